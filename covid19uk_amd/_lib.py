@@ -1,0 +1,90 @@
+"""ctypes binding of libseirhip.so (C-ABI: include/seir_hip.h).
+
+There is no CPU fallback: if the shared library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C
+covid19uk_amd/csrc`) or no HIP device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseirhip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class SeirDesc(ctypes.Structure):
+    """Mirror of `seir_desc` (include/seir_hip.h)."""
+    _fields_ = [
+        ("M", ctypes.c_int32), ("T", ctypes.c_int32),
+        ("max_chains", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("Cstar", c_double_p), ("N", c_double_p), ("W", c_double_p),
+        ("weekday_c", c_double_p), ("log_area_c", c_double_p),
+        ("car_Q", c_double_p), ("car_half_logdet", ctypes.c_double),
+        ("init_state", c_double_p),
+        ("nu", ctypes.c_double), ("time_delta", ctypes.c_double),
+        ("rate_floor", ctypes.c_double),
+    ]
+
+
+class SeirError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/seir_hip.h declares
+_SIGNATURES = {
+    "seir_abi_version": (ctypes.c_int, []),
+    "seir_last_error": (ctypes.c_char_p, []),
+    "seir_create": (ctypes.c_int, [ctypes.POINTER(SeirDesc), c_void_pp]),
+    "seir_destroy": (None, [ctypes.c_void_p]),
+    "seir_num_params": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_log_prob": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
+    "seir_log_prob_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p,
+                                          c_double_p, c_double_p]),
+    "seir_log_prob_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 4),
+    "seir_prepare_events_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "seir_eval_prepared_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 3),
+    "seir_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "seir_malloc": (ctypes.c_int, [c_void_pp, ctypes.c_uint64]),
+    "seir_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_memcpy_h2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "seir_memcpy_d2h": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "seir_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "seir_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.POINTER(ctypes.c_float)]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libseirhip.so (once).  Raises SeirError if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SeirError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). "
+                "This package has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().seir_last_error()
+        raise SeirError(f"libseirhip call failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,147 @@
+"""`SeirModel`: the device-resident counterpart of the reference's
+`model = CovidUK(covariates, initial_state, initial_step=0, num_steps=T)`
+together with the `joint_log_prob(unconstrained_params, events)` closure built
+on it (covid19uk/inference/inference.py:518-557).
+
+All arithmetic happens in libseirhip.so (HIP, gfx950) through the C-ABI of
+include/seir_hip.h; this class only marshals arrays.  PyTorch is used purely as
+a device-memory container for the `*_dev` methods.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import model_spec as ms
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+class SeirModel:
+    def __init__(self, covariates: ms.Covariates, initial_state, max_chains: int = 1, device: int = 0):
+        self._lib = _lib.load()
+        self._ctx = ctypes.c_void_p()
+        k = ms.derive_constants(covariates)
+        self.M, self.T = covariates.M, covariates.T
+        self.P = ms.num_params(self.M, self.T)
+        self.max_chains = int(max_chains)
+        self.device = int(device)
+        init = np.ascontiguousarray(initial_state, dtype=np.float64)
+        if init.shape != (self.M, 4):
+            raise ValueError(f"initial_state must be [M,4]=({self.M},4), got {init.shape}")
+        self.initial_state = init
+        keep = dict(Cstar=np.ascontiguousarray(k.Cstar), N=np.ascontiguousarray(k.N),
+                    W=np.ascontiguousarray(k.W), wd=np.ascontiguousarray(k.weekday_c),
+                    la=np.ascontiguousarray(k.log_area_c), Q=np.ascontiguousarray(k.car_Q))
+        desc = _lib.SeirDesc(
+            M=self.M, T=self.T, max_chains=self.max_chains, device=self.device,
+            Cstar=_dptr(keep["Cstar"]), N=_dptr(keep["N"]), W=_dptr(keep["W"]),
+            weekday_c=_dptr(keep["wd"]), log_area_c=_dptr(keep["la"]), car_Q=_dptr(keep["Q"]),
+            car_half_logdet=k.car_half_logdet, init_state=_dptr(init),
+            nu=ms.NU, time_delta=ms.TIME_DELTA, rate_floor=ms.RATE_FLOOR)
+        _lib.check(self._lib.seir_create(ctypes.byref(desc), ctypes.byref(self._ctx)))
+        assert self._lib.seir_num_params(self._ctx) == self.P
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.seir_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- host-array entry points ---------------------------------------------
+    def _batch(self, u, events):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        ev = np.ascontiguousarray(events, dtype=np.float64)
+        single = u.ndim == 1
+        if single:
+            u, ev = u[None], ev[None]
+        B = u.shape[0]
+        if u.shape != (B, self.P):
+            raise ValueError(f"u must be [B,{self.P}], got {u.shape}")
+        if ev.shape != (B, self.M, self.T, 3):
+            raise ValueError(f"events must be [B,{self.M},{self.T},3], got {ev.shape}")
+        return u, ev, B, single
+
+    def log_prob(self, u, events):
+        """joint_log_prob(u, events) (inference.py:537-557); batched over a leading axis."""
+        u, ev, B, single = self._batch(u, events)
+        out = np.empty(B)
+        _lib.check(self._lib.seir_log_prob(self._ctx, B, _dptr(u), _dptr(ev), _dptr(out)))
+        return float(out[0]) if single else out
+
+    def log_prob_grad(self, u, events):
+        """Value and d/du (the reference differentiates joint_log_prob with TF autodiff)."""
+        u, ev, B, single = self._batch(u, events)
+        out, g = np.empty(B), np.empty((B, self.P))
+        _lib.check(self._lib.seir_log_prob_grad(self._ctx, B, _dptr(u), _dptr(ev), _dptr(out), _dptr(g)))
+        return (float(out[0]), g[0]) if single else (out, g)
+
+    # -- device-tensor entry points (torch tensors on cuda:<device>, float64) --
+    @staticmethod
+    def _tptr(t, shape):
+        import torch
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError("expected a contiguous float64 CUDA tensor")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _torch_ready(self):
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def log_prob_dev(self, u_t, events_t, logp_t, grad_t=None):
+        """Asynchronous on the context stream; call sync() before reading outputs."""
+        B = u_t.shape[0]
+        self._torch_ready()
+        _lib.check(self._lib.seir_log_prob_dev(
+            self._ctx, B, self._tptr(u_t, (B, self.P)), self._tptr(events_t, (B, self.M, self.T, 3)),
+            self._tptr(logp_t, (B,)), None if grad_t is None else self._tptr(grad_t, (B, self.P))))
+
+    def prepare_events_dev(self, events_t):
+        B = events_t.shape[0]
+        self._torch_ready()
+        _lib.check(self._lib.seir_prepare_events_dev(
+            self._ctx, B, self._tptr(events_t, (B, self.M, self.T, 3))))
+
+    def eval_prepared_dev(self, u_t, logp_t, grad_t=None):
+        B = u_t.shape[0]
+        _lib.check(self._lib.seir_eval_prepared_dev(
+            self._ctx, B, self._tptr(u_t, (B, self.P)), self._tptr(logp_t, (B,)),
+            None if grad_t is None else self._tptr(grad_t, (B, self.P))))
+
+    def sync(self):
+        _lib.check(self._lib.seir_sync(self._ctx))
+
+    # -- timing (HIP events on the context stream) ----------------------------
+    def timer_start(self):
+        _lib.check(self._lib.seir_timer_start(self._ctx))
+
+    def timer_stop(self) -> float:
+        ms_ = ctypes.c_float()
+        _lib.check(self._lib.seir_timer_stop(self._ctx, ctypes.byref(ms_)))
+        return float(ms_.value)
+
+    KERNELS = {"scan": 0, "gemm": 1, "se_value": 2, "se_grad": 3, "finish": 4}
+
+    def time_kernel(self, which: str, B: int, iters: int = 50) -> float:
+        """Mean launch duration (ms) of one kernel of the last evaluation."""
+        ms_ = ctypes.c_float()
+        _lib.check(self._lib.seir_time_kernel(self._ctx, self.KERNELS[which], B, iters, ctypes.byref(ms_)))
+        return float(ms_.value)

@@ -1,0 +1,127 @@
+/* seir_hip.h -- C-ABI of libseirhip.so, the MI355X (gfx950) implementation of the
+ * covid19uk spatial SEIR posterior hot path.
+ *
+ * The reference has no FFI for this path: the seam is the Python callable
+ *     joint_log_prob(unconstrained_params[P], events[M,T,3]) -> scalar
+ * (covid19uk/inference/inference.py:537-557) handed to the Gibbs/HMC/MH kernels
+ * (inference.py:97-101, mcmc_kernel_factory.py:14-168), and below it
+ *     DiscreteTimeStateTransitionModel(...).log_prob(events)
+ * (covid19uk/model_spec.py:278-285).  Each entry point below names the
+ * reference interface it stands in for.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative seir_status on
+ *     failure; seir_last_error() then returns a thread-local message;
+ *   - the caller owns every host buffer, nothing is retained past the call;
+ *   - a context owns its device buffers and one HIP stream, is bound to one
+ *     device and is not thread-safe;
+ *   - no exceptions, no global mutable state, no torch types;
+ *   - layouts are the reference's: events[B][M][T][3] (M-major, fp64 counts),
+ *     u[B][P] with P = 6 + (T-1) + M ordered psi, sigma_space, beta_area,
+ *     gamma0, gamma1, alpha_0, alpha_t[T-1], spatial_effect[M]
+ *     (inference.py:541-552); psi and sigma_space are unconstrained by
+ *     softplus + eps (inference.py:525-535).
+ *   - there is NO CPU fallback: without a HIP device seir_create fails.
+ */
+#ifndef SEIR_HIP_H
+#define SEIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEIR_ABI_VERSION 1
+
+typedef enum {
+    SEIR_OK = 0,
+    SEIR_ERR_INVALID = -1,   /* bad argument / shape */
+    SEIR_ERR_DEVICE = -2,    /* HIP runtime failure (no device, OOM, launch error) */
+    SEIR_ERR_STATE = -3      /* call made in the wrong state */
+} seir_status;
+
+typedef struct seir_ctx seir_ctx;
+typedef struct seir_sampler seir_sampler;
+
+/* Everything `seir()`'s closure holds that does not depend on parameters
+ * (model_spec.py:216-230), the CAR precision of spatial_effect() (:171-175),
+ * the initial state handed to CovidUK (:139) and the constants of :22-26.
+ * All pointers are host pointers, copied during seir_create. */
+typedef struct {
+    int32_t M;                 /* metapopulations (LADs) */
+    int32_t T;                 /* time steps (days) */
+    int32_t max_chains;        /* largest batch B any later call will use */
+    int32_t device;            /* HIP device ordinal */
+    const double *Cstar;       /* [M*M] row-major: C+C^T, diag = -colsum(C)  (:216-219) */
+    const double *N;           /* [M] population */
+    const double *W;           /* [T] commute volume (:221) */
+    const double *weekday_c;   /* [T] centred weekday (:224-225) */
+    const double *log_area_c;  /* [M] centred log(area/1e8) (:228-230) */
+    const double *car_Q;       /* [M*M] D_w - 0.25 W_adj (:172-175) */
+    double car_half_logdet;    /* 0.5*logdet(car_Q) */
+    const double *init_state;  /* [M*4] S,E,I,R at step 0 (inference.py:511) */
+    double nu;                 /* E->I rate, 0.28 (:26) */
+    double time_delta;         /* 1.0 (:25) */
+    double rate_floor;         /* 1e-9 (:264-266) */
+} seir_desc;
+
+int seir_abi_version(void);
+const char *seir_last_error(void);
+
+/* CovidUK(covariates, initial_state, initial_step=0, num_steps=T)  (model_spec.py:139) */
+int seir_create(const seir_desc *desc, seir_ctx **out);
+void seir_destroy(seir_ctx *ctx);
+int seir_num_params(const seir_ctx *ctx);          /* P */
+
+/* joint_log_prob(unconstrained_params, events) for a batch of B chains
+ * (inference.py:537-557).  Host pointers; blocking. */
+int seir_log_prob(seir_ctx *ctx, int32_t B, const double *u, const double *events,
+                  double *logp /* [B] */);
+
+/* The same value plus d/du, which the reference obtains by TF autodiff inside
+ * PreconditionedHamiltonianMonteCarlo (mcmc_kernel_factory.py:21-27). */
+int seir_log_prob_grad(seir_ctx *ctx, int32_t B, const double *u, const double *events,
+                       double *logp /* [B] */, double *grad /* [B*P] */);
+
+/* Device-pointer form of the two calls above: asynchronous on the context's
+ * stream, no host copies.  grad_dev may be NULL (value only). */
+int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, const double *events_dev,
+                      double *logp_dev, double *grad_dev);
+
+/* Stage split used when many parameter vectors are evaluated against the same
+ * events (the 16 leapfrogs of one HMC step): `prepare` runs the parameter-free
+ * part (state scan, binomial coefficients, mobility contraction F = Cstar.I/N),
+ * `eval_prepared` only the parameter-dependent part. */
+int seir_prepare_events_dev(seir_ctx *ctx, int32_t B, const double *events_dev);
+int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_dev,
+                           double *logp_dev, double *grad_dev);
+
+int seir_sync(seir_ctx *ctx);
+void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context */
+
+/* Device memory helpers so that a ctypes host can keep inputs resident
+ * without torch (torch tensors' data_ptr() work just as well). */
+int seir_malloc(void **dev_ptr, uint64_t bytes);
+int seir_free(void *dev_ptr);
+int seir_memcpy_h2d(void *dst_dev, const void *src_host, uint64_t bytes);
+int seir_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t bytes);
+
+/* HIP-event timing on the context's stream (torch.cuda.Event only sees
+ * torch's own streams).  start/stop bracket whatever was enqueued between
+ * them; stop blocks and returns milliseconds. */
+int seir_timer_start(seir_ctx *ctx);
+int seir_timer_stop(seir_ctx *ctx, float *ms);
+
+/* Per-kernel timing: launches kernel `which` `iters` times back to back on the
+ * context stream with the arguments of the last evaluation and returns the
+ * mean launch duration in milliseconds (HIP events). */
+enum { SEIR_K_SCAN = 0, SEIR_K_GEMM = 1, SEIR_K_SE_VALUE = 2, SEIR_K_SE_GRAD = 3,
+       SEIR_K_FINISH = 4 };
+int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t iters, float *mean_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEIR_HIP_H */

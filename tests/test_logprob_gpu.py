@@ -1,0 +1,175 @@
+"""GPU parity: libseirhip's joint log-probability and gradient, called through
+the C-ABI, against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64): |dlogp| <= 1e-9 |logp| (measured ~1e-13),
+gradient rtol 1e-6 against the analytic oracle gradient (measured ~1e-11)."""
+import numpy as np
+import pytest
+
+from covid19uk_amd import synth
+from oracle import seir_oracle as so
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LOGP = 1e-9
+RTOL_GRAD = 1e-6
+
+
+@pytest.fixture(scope="module")
+def Model():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import __graft_entry__ as entry
+    entry.build()
+    from covid19uk_amd.seir import SeirModel
+    return SeirModel
+
+
+def _batch(case, B, seed):
+    T = case["k"].T
+    u = synth.jitter_params(case["u"], B, seed=seed, T=T)
+    rng = np.random.default_rng(seed)
+    u[:, 6:6 + T - 1] = 0.005 * rng.normal(size=(B, T - 1))
+    ev = np.stack([case["events"]] * B)
+    return u, ev
+
+
+def _check(case, model, u, ev, grad=True, use_c=False):
+    k = case["k"]
+    if grad:
+        lp, g = model.log_prob_grad(u, ev)
+    else:
+        lp, g = model.log_prob(u, ev), None
+    for b in range(u.shape[0]):
+        if use_c:
+            want, gw = H.c_oracle_eval(k, u[b], ev[b], stable=1, want_grad=True)
+        else:
+            want, gw = so.joint_log_prob_and_grad(u[b], ev[b], k)
+        assert abs(lp[b] - want) <= RTOL_LOGP * abs(want), (b, lp[b], want)
+        if grad:
+            scale = np.maximum(np.abs(gw), 1e-6 * np.abs(gw).max())
+            err = np.max(np.abs(g[b] - gw) / scale)
+            assert err < RTOL_GRAD, (b, err)
+    return lp
+
+
+@pytest.mark.parametrize("name,seed,B", [("micro_1x1", 1, 1), ("micro_2x3", 2, 3), ("micro_3x5", 3, 2),
+                                         ("micro_17x70", 4, 2), ("ni11", 5, 16)])
+def test_small_cases_match_numpy_oracle(Model, name, seed, B):
+    case = H.build_case(name, seed, alpha_t_sd=0.005)
+    u, ev = _batch(case, B, seed)
+    with Model(case["cov"], case["init"], max_chains=B) as model:
+        lp = _check(case, model, u, ev, grad=True)
+        lp2 = model.log_prob(u, ev)
+        assert np.array_equal(lp, lp2), "value-only and value+grad paths disagree"
+
+
+def test_value_only_matches_reference_formulation(Model):
+    # the oracle's 'reference' form evaluates log(1-(1-e^-r)) naively as TFP does
+    case = H.build_case("ni11", 6)
+    u, ev = _batch(case, 4, 6)
+    with Model(case["cov"], case["init"], max_chains=4) as model:
+        lp = model.log_prob(u, ev)
+    for b in range(4):
+        want = so.joint_log_prob(u[b], ev[b], case["k"], "reference")
+        assert abs(lp[b] - want) <= RTOL_LOGP * abs(want)
+
+
+def test_distinct_events_per_chain(Model):
+    case = H.build_case("ni11", 7)
+    u, ev = _batch(case, 3, 7)
+    other = H.build_case("ni11", 8)
+    ev[1] = other["events"]          # feasible under its own init only -> may be -inf; use own init
+    ev[2, 3, 10, 0] += 2             # perturb one cell
+    with Model(case["cov"], case["init"], max_chains=3) as model:
+        lp = model.log_prob(u, ev)
+    for b in range(3):
+        want = so.joint_log_prob(u[b], ev[b], case["k"], "stable")
+        if np.isfinite(want):
+            assert abs(lp[b] - want) <= RTOL_LOGP * abs(want)
+        else:
+            assert lp[b] == want or (np.isnan(lp[b]) and np.isnan(want))
+
+
+def test_infeasible_events_are_minus_inf(Model):
+    case = H.build_case("micro_2x3", 9)
+    ev = case["events"].copy()
+    ev[0, 1, 1] = 1e6
+    with Model(case["cov"], case["init"]) as model:
+        assert model.log_prob(case["u"], ev) == -np.inf
+
+
+def test_negative_rate_semantics(Model):
+    # lam<0 with k_se=0 stays finite (multiply_no_nan), with k_se>0 is NaN -> MH rejects
+    from covid19uk_amd import model_spec as ms
+    cov = ms.Covariates(C=np.array([[0.0, 50.0], [50.0, 0.0]]), W=np.ones(1), N=np.array([100.0, 100.0]),
+                        adjacency=np.array([[0.0, 1.0], [1.0, 0.0]]), weekday=np.ones(1),
+                        area=np.array([1e8, 1e8]))
+    init = np.array([[90.0, 0.0, 10.0, 0.0], [100.0, 0.0, 0.0, 0.0]])
+    k = H.oracle_constants(cov, init)
+    theta = np.array([5.0, 0.1, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0])
+    u = synth.unconstrain(theta)
+    ev = np.zeros((2, 1, 3))
+    with Model(cov, init) as model:
+        got = model.log_prob(u, ev)
+        want = so.joint_log_prob(u, ev, k)
+        assert np.isfinite(want) and abs(got - want) <= RTOL_LOGP * abs(want)
+        ev[0, 0, 0] = 1.0
+        assert np.isnan(model.log_prob(u, ev))
+
+
+def test_uk380_batch_matches_c_oracle(Model):
+    case = H.build_case("uk380", 10, alpha_t_sd=0.005)
+    u, ev = _batch(case, 8, 10)
+    with Model(case["cov"], case["init"], max_chains=8) as model:
+        _check(case, model, u, ev, grad=True, use_c=True)
+
+
+def test_prepared_path_and_linearity_properties_at_full_size(Model):
+    """Size-independent properties at the BASELINE size (UK-380 x 365, 8 chains):
+    (1) prepare+eval == one-shot; (2) chains are independent: permuting the batch
+    permutes the outputs bit-for-bit; (3) the log-prob of relabelled LADs is invariant."""
+    import torch
+    case = H.build_case("uk380", 11)
+    B = 8
+    u, ev = _batch(case, B, 11)
+    dev = torch.device("cuda:0")
+    ut, evt = torch.tensor(u, device=dev), torch.tensor(ev, device=dev)
+    lp1 = torch.empty(B, dtype=torch.float64, device=dev)
+    lp2 = torch.empty_like(lp1)
+    g1 = torch.empty(B, u.shape[1], dtype=torch.float64, device=dev)
+    g2 = torch.empty_like(g1)
+    with Model(case["cov"], case["init"], max_chains=B) as model:
+        model.log_prob_dev(ut, evt, lp1, g1)
+        model.sync()
+        model.prepare_events_dev(evt)
+        model.eval_prepared_dev(ut, lp2, g2)
+        model.sync()
+        assert torch.equal(lp1, lp2) and torch.equal(g1, g2)
+        perm = torch.tensor([3, 1, 7, 0, 2, 6, 5, 4], device=dev)
+        model.log_prob_dev(ut[perm].contiguous(), evt[perm].contiguous(), lp2, g2)
+        model.sync()
+        assert torch.equal(lp1[perm], lp2) and torch.equal(g1[perm], g2)
+    # relabelling invariance through a second context
+    cov, k = case["cov"], case["k"]
+    rp = np.random.default_rng(0).permutation(k.M)
+    from covid19uk_amd import model_spec as ms
+    cov2 = ms.Covariates(C=cov.C[np.ix_(rp, rp)], W=cov.W, N=cov.N[rp], adjacency=cov.adjacency[np.ix_(rp, rp)],
+                         weekday=cov.weekday, area=cov.area[rp])
+    u2 = u[:1].copy()
+    u2[0, 6 + k.T - 1:] = u[0, 6 + k.T - 1:][rp]
+    with Model(cov2, case["init"][rp]) as model2:
+        b = model2.log_prob(u2, ev[:1, rp])
+    a = float(lp1[0].cpu())
+    assert abs(a - b[0]) <= 1e-11 * abs(a)
+
+
+def test_argument_errors(Model):
+    from covid19uk_amd import _lib
+    case = H.build_case("micro_2x3", 12)
+    with Model(case["cov"], case["init"], max_chains=1) as model:
+        with pytest.raises(ValueError):
+            model.log_prob(case["u"][:-1], case["events"])
+        with pytest.raises(_lib.SeirError):
+            model.log_prob(np.stack([case["u"]] * 2), np.stack([case["events"]] * 2))   # B > max_chains
