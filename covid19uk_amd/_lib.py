@@ -30,6 +30,23 @@ class SeirDesc(ctypes.Structure):
     ]
 
 
+class SeirSamplerDesc(ctypes.Structure):
+    """Mirror of `seir_sampler_desc` (include/seir_hip.h)."""
+    _fields_ = [
+        ("num_chains", ctypes.c_int32),
+        ("dmax", ctypes.c_int32), ("nmax", ctypes.c_int32), ("m", ctypes.c_int32),
+        ("occult_nmax", ctypes.c_int32), ("num_event_time_updates", ctypes.c_int32),
+        ("t_range_lo", ctypes.c_int32), ("t_range_hi", ctypes.c_int32),
+        ("num_leapfrog_steps", ctypes.c_int32), ("trace_capacity", ctypes.c_int32),
+        ("first_chain_id", ctypes.c_int32), ("record_events", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+    ]
+
+
+MMAX = 4                      # SEIR_MMAX
+MOVE_TRACE = 2 + 4 * MMAX     # SEIR_MOVE_TRACE
+
+
 class SeirError(RuntimeError):
     pass
 
@@ -57,6 +74,20 @@ _SIGNATURES = {
     "seir_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "seir_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.POINTER(ctypes.c_float)]),
+    "seir_sampler_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SeirSamplerDesc), c_void_pp]),
+    "seir_sampler_destroy": (None, [ctypes.c_void_p]),
+    "seir_sampler_set_state": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
+    "seir_sampler_get_state": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "seir_sampler_set_kernel": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
+    "seir_sampler_get_kernel": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
+    "seir_sampler_set_adaptation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.c_int32, ctypes.c_double, c_double_p, c_double_p,
+                                                   c_double_p]),
+    "seir_sampler_refresh": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_sampler_reset_trace": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_sampler_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "seir_sampler_read_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_double_p,
+                                               ctypes.POINTER(ctypes.c_int32), c_double_p, c_double_p]),
 }
 
 _lib = None

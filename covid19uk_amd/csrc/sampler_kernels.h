@@ -1,0 +1,697 @@
+// Device-resident Metropolis-within-Gibbs sweep for B chains (one posterior draw
+// per chain per sweep), re-stating on MI355X what the reference builds from
+//   GibbsKernel[ HMC(u | events),  MultiScan(num_event_time_updates,
+//       Gibbs[ MH(EventTimesUpdate S->E), MH(EventTimesUpdate E->I),
+//              MH(OccultUpdate S->E),     MH(OccultUpdate E->I) ]) ]
+// (covid19uk/inference/inference.py:86-101,219-228;
+//  covid19uk/inference/mcmc_kernel_factory.py:14-168).
+//
+// Chain state lives in HBM: int32 event planes K[3] and state planes St[3]
+// ([B][Mp][Tp], T contiguous), the cached mobility contraction F = Cstar.I/N,
+// the per-day I->R statistics, and the HMC position/momentum vectors.  The
+// reference re-evaluates the full target for every MH proposal
+// (mcmc_kernel_factory.py:72-83,99-110); here a proposal's log-ratio is
+// evaluated over the cells it changes (k_move_delta) and F is updated by a
+// rank-1 column update on acceptance.  tests/test_sampler_gpu.py checks the
+// running log-prob against a full re-evaluation.
+//
+// The proposal distributions re-state gemlib's UncalibratedEventTimesUpdate /
+// UncalibratedOccultUpdate as documented in DESIGN.md ("MCMC kernels"); the
+// same definitions are implemented by the CPU oracle oracle/mcmc_oracle.py with
+// the same Philox stream, so traces are comparable draw by draw.
+#pragma once
+#include "logprob_kernels.h"
+#include "philox.h"
+
+namespace seir {
+
+constexpr int MMAX = 4;           // upper bound on config["m"]
+constexpr int NHS = 32;           // per-chain HMC scalar block
+enum {
+    HS_EPS = 0,       // step size used by the current/next HMC step
+    HS_LP_THETA,      // prior + jac + S->E + I->R terms at (q, events)
+    HS_LP_CONST,      // binomial coefficients + E->I term (parameter free)
+    HS_LP0,           // HS_LP_THETA at the start of the trajectory
+    HS_K0,            // kinetic energy at the start
+    HS_DA_ERR, HS_DA_STEP, HS_DA_LOGAVG, HS_DA_MU,
+    HS_RV_N,          // running-variance sample count
+    HS_ACC,           // last HMC accept flag
+    HS_LOGACC         // last log accept ratio
+};
+
+struct SamplerCfg {
+    int B, dmax, nmax, mmax, occult_nmax, n_scans, tr_lo, tr_hi, L;
+    uint32_t k0, k1;
+    int chain0;
+    int adapt_step, adapt_mass, n_adapt;
+    double target_accept;
+    int cap;          // trace slots
+    int nrb_d;        // row blocks of k_move_delta / k_move_pa
+};
+
+struct Move {
+    int valid, n, tgt, kind;          // kind 0 = event-time move, 1 = occult
+    int m[MMAX], a[MMAX], b[MMAX];    // row; day the events leave / occult day; arrival day (-1 none)
+    int dka[MMAX], dkb[MMAX];         // change of K[tgt] at a, b
+    int lo[MMAX], hi[MMAX];           // state days (lo, hi] change
+    int dsrc[MMAX];                   // change of the source compartment there; dest gets -dsrc
+    int LO, HI;                       // hull of touched days [LO, HI]
+    int any_dI;
+    int slot;                         // which of the 4 sub-kernels (trace column)
+    int tm[MMAX], tt[MMAX], tdt[MMAX], tx[MMAX];
+    double logq, logu;
+};
+
+constexpr int NMVTR = 2 + 4 * MMAX;   // is_accepted, target_log_prob, m[], t[], delta_t[], x_star[]
+
+struct Chains {
+    double *q, *p, *q0, *grad, *var, *rv_mean, *rv_m2;   // [B][Pp]
+    double *hs;                                          // [B][NHS]
+    Move *mv;                                            // [2][B] double-buffered proposal descriptors
+    double *Dpart;                                       // [B][nrb_d][2]
+    unsigned *sweep;                                     // [B] sweeps done (device resident: graph replays advance it)
+    unsigned *slot0;                                     // [1] sweep index of trace slot 0
+    // traces
+    double *tr_theta;                                    // [cap][B][P]
+    int *tr_events;                                      // [cap][B][M][T][3]
+    double *tr_hmc;                                      // [cap][B][3]  is_accepted, target_log_prob, step_size
+    double *tr_mv;                                       // [cap][B][4][NMVTR]
+};
+
+__device__ inline RngKey rng_key(const SamplerCfg &s, const Chains &ch, int b) {
+    return RngKey{s.k0, s.k1, (uint32_t)(s.chain0 + b), ch.sweep[b]};
+}
+
+// ---------------------------------------------------------------------------
+// events fp64 [B][M][T][3]  <->  int32 planes
+// ---------------------------------------------------------------------------
+__global__ void k_import_events(Dims d, Work w, const double *__restrict__ events, int B) {
+    const size_t n = (size_t)B * d.M * d.T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % d.T);
+        const int m = (int)((i / d.T) % d.M);
+        const int b = (int)(i / ((size_t)d.T * d.M));
+        const size_t q = ((size_t)b * d.Mp + m) * d.Tp + t;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) w.K[x][q] = (int)events[i * 3 + x];
+    }
+}
+
+__global__ void k_export_events(Dims d, Work w, double *__restrict__ events, int B) {
+    const size_t n = (size_t)B * d.M * d.T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % d.T);
+        const int m = (int)((i / d.T) % d.M);
+        const int b = (int)(i / ((size_t)d.T * d.M));
+        const size_t q = ((size_t)b * d.Mp + m) * d.Tp + t;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) events[i * 3 + x] = (double)w.K[x][q];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// HMC.  PreconditionedHamiltonianMonteCarlo with a diagonal mass matrix
+// M = diag(1/var) (mcmc_kernel_factory.py:14-29; num_leapfrog_steps=16,
+// inference.py:324-329), DualAveragingStepSizeAdaptation (:32-44) and
+// DiagonalMassMatrixAdaptation (:47-60) as re-stated in DESIGN.md.
+// One workgroup per chain.  STAGE 0: first kernel of the trajectory (fresh
+// gradient at the current point, momentum draw, first half kick + drift);
+// STAGE 1: interior leapfrog; STAGE 2: last half kick, accept/reject, adaptation.
+// Every stage ends by refreshing the parameter tables for the new position.
+// ---------------------------------------------------------------------------
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_hmc_step(Dims d, Consts c, Work w, SamplerCfg s, Chains ch) {
+    extern __shared__ double lds_col[];             // [Tp]
+    __shared__ double sh[4];
+    __shared__ double seg[256];
+    __shared__ int s_accept;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp, *g = ch.grad + (size_t)b * d.Pp;
+    double *q0 = ch.q0 + (size_t)b * d.Pp;
+    const double *var = ch.var + (size_t)b * d.Pp;
+    double *hs = ch.hs + (size_t)b * NHS;
+    const double *sc = w.scal + (size_t)b * NSCAL;
+
+    // gradient and parameter-dependent log-prob at the current position
+    const double lik = reduce_chain<true>(d, c, w, b, q, g, lds_col, seg, sh);
+    const double lp_theta = lik + sc[SC_PRIOR] + sc[SC_JAC];
+    const double eps = hs[HS_EPS];
+    __syncthreads();                                  // g[] visible to all threads
+
+    if (STAGE == 0) {
+        const RngKey key = rng_key(s, ch, b);
+        double k0 = 0.0;
+        for (int i2 = tid; i2 * 2 < d.P; i2 += 256) {
+            double u1, u2;
+            rng_uniform2(key, RS_MOMENTUM, (uint32_t)i2, u1, u2);
+            const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+            const double z[2] = {rad * cos(ang), rad * sin(ang)};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = i2 * 2 + j;
+                if (i >= d.P) break;
+                const double v = var[i];
+                double pi = z[j] / sqrt(v);           // p ~ N(0, diag(1/var))
+                k0 += 0.5 * v * pi * pi;
+                q0[i] = q[i];
+                pi += 0.5 * eps * g[i];
+                p[i] = pi;
+                q[i] += eps * v * pi;
+            }
+        }
+        k0 = block_sum_256(k0, sh);
+        if (tid == 0) { hs[HS_LP0] = lp_theta; hs[HS_K0] = k0; }
+    } else if (STAGE == 1) {
+        for (int i = tid; i < d.P; i += 256) {
+            const double pi = p[i] + eps * g[i];
+            p[i] = pi;
+            q[i] += eps * var[i] * pi;
+        }
+    } else {
+        double k1 = 0.0;
+        for (int i = tid; i < d.P; i += 256) {
+            const double pi = p[i] + 0.5 * eps * g[i];
+            p[i] = pi;
+            k1 += 0.5 * var[i] * pi * pi;
+        }
+        k1 = block_sum_256(k1, sh);
+        if (tid == 0) {
+            const RngKey key = rng_key(s, ch, b);
+            double u1, u2;
+            rng_uniform2(key, RS_HMC_ACCEPT, 0u, u1, u2);
+            const double log_ratio = (lp_theta - hs[HS_LP0]) - (k1 - hs[HS_K0]);
+            const int acc = log(u1) < log_ratio ? 1 : 0;      // NaN compares false -> reject
+            s_accept = acc;
+            hs[HS_ACC] = (double)acc;
+            hs[HS_LOGACC] = log_ratio;
+            hs[HS_LP_THETA] = acc ? lp_theta : hs[HS_LP0];
+            const unsigned slot = ch.sweep[b] - ch.slot0[0];
+            if (slot < (unsigned)s.cap) {
+                double *tr = ch.tr_hmc + ((size_t)slot * s.B + b) * 3;
+                tr[0] = (double)acc;
+                tr[1] = hs[HS_LP_THETA] + hs[HS_LP_CONST];
+                tr[2] = eps;
+            }
+            if (s.adapt_step) {                       // dual averaging (Hoffman & Gelman alg. 5, TFP defaults)
+                const double a = isfinite(log_ratio) ? fmin(1.0, exp(log_ratio)) : 0.0;
+                const double prev_step = hs[HS_DA_STEP];
+                const double n = prev_step + 1.0;
+                const double err = hs[HS_DA_ERR] + s.target_accept - a;
+                const double log_step = hs[HS_DA_MU] - err * sqrt(n) / ((n + 10.0) * 0.05);
+                const double eta = pow(n, -0.75);
+                const double log_avg = eta * log_step + (1.0 - eta) * hs[HS_DA_LOGAVG];
+                hs[HS_DA_ERR] = err; hs[HS_DA_STEP] = n; hs[HS_DA_LOGAVG] = log_avg;
+                if (prev_step <= (double)s.n_adapt)
+                    hs[HS_EPS] = prev_step < (double)s.n_adapt ? exp(log_step) : exp(log_avg);
+            }
+        }
+        __syncthreads();
+        const bool acc = s_accept != 0;
+        if (!acc)
+            for (int i = tid; i < d.P; i += 256) q[i] = q0[i];
+        if (s.adapt_mass) {                           // Welford update with the new state (ddof 0)
+            const double n1 = hs[HS_RV_N] + 1.0;
+            double *mean = ch.rv_mean + (size_t)b * d.Pp, *m2 = ch.rv_m2 + (size_t)b * d.Pp;
+            double *varw = ch.var + (size_t)b * d.Pp;
+            for (int i = tid; i < d.P; i += 256) {
+                const double x = acc ? q[i] : q0[i];
+                const double dlt = x - mean[i];
+                const double mu = mean[i] + dlt / n1;
+                const double ss = m2[i] + dlt * (x - mu);
+                mean[i] = mu; m2[i] = ss;
+                varw[i] = ss / n1;
+            }
+            __syncthreads();
+            if (tid == 0) hs[HS_RV_N] = n1;
+        }
+    }
+    __syncthreads();
+    param_tables(d, c, w, b, q, seg, sh);
+    if (STAGE == 2 && tid == 0) {
+        // constrained draw -> trace (param_bijector.inverse(draws[0]), inference.py:375)
+        const unsigned slot = ch.sweep[b] - ch.slot0[0];
+        if (slot < (unsigned)s.cap) {
+            double *tr = ch.tr_theta + ((size_t)slot * s.B + b) * d.P;
+            tr[0] = sc[SC_PSI];
+            tr[1] = sc[SC_SIG];
+        }
+    }
+    if (STAGE == 2) {
+        const unsigned slot = ch.sweep[b] - ch.slot0[0];
+        if (slot < (unsigned)s.cap) {
+            double *tr = ch.tr_theta + ((size_t)slot * s.B + b) * d.P;
+            for (int i = 2 + tid; i < d.P; i += 256) tr[i] = q[i];
+        }
+    }
+}
+
+// Parameter tables + full parameter-dependent log-prob for the current state
+// (used when the state is (re)loaded): one workgroup per chain, after k_se<false,1>.
+__global__ __launch_bounds__(256) void k_chain_refresh(Dims d, Consts c, Work w, Chains ch) {
+    extern __shared__ double lds_col[];
+    __shared__ double sh[4];
+    __shared__ double seg[256];
+    const int b = blockIdx.x;
+    const double lik = reduce_chain<false>(d, c, w, b, ch.q + (size_t)b * d.Pp, nullptr, lds_col, seg, sh);
+    if (threadIdx.x == 0) {
+        const double *sc = w.scal + (size_t)b * NSCAL;
+        ch.hs[(size_t)b * NHS + HS_LP_THETA] = lik + sc[SC_PRIOR] + sc[SC_JAC];
+        ch.hs[(size_t)b * NHS + HS_LP_CONST] = w.constsum[b];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chain_tables(Dims d, Consts c, Work w, Chains ch) {
+    __shared__ double sh[4];
+    __shared__ double seg[256];
+    param_tables(d, c, w, blockIdx.x, ch.q + (size_t)blockIdx.x * d.Pp, seg, sh);
+}
+
+// ---------------------------------------------------------------------------
+// Event moves.
+// ---------------------------------------------------------------------------
+// state of compartment `comp` of row m at the start of day tau, tau in [0, T]
+// (tau == T: state after the last day, i.e. the closed end of the series)
+__device__ inline int comp_start(const Dims &d, const Work &w, size_t rowoff, int comp, int tau) {
+    if (tau < d.T) return w.St[comp][rowoff + tau];
+    const int t = d.T - 1;
+    int v = w.St[comp][rowoff + t];
+    if (comp == 0) v -= w.K[0][rowoff + t];
+    else if (comp == 1) v += w.K[0][rowoff + t] - w.K[1][rowoff + t];
+    else v += w.K[1][rowoff + t] - w.K[2][rowoff + t];
+    return v;
+}
+
+// block-wide helpers over a 256-thread workgroup -----------------------------
+__device__ inline int block_sum_int(int v, int *sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ inline int block_min_int(int v, int *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, WAVE));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return min(min(sh[0], sh[1]), min(sh[2], sh[3]));
+}
+
+// Index of the r-th (0-based) element with flag set among n elements, where
+// element i's flag is flag(i).  Each thread owns a contiguous segment.
+// Returns -1 if r >= count.  `count_out` receives the number of set flags.
+template <typename FlagFn>
+__device__ inline int block_select(int n, int r, FlagFn flag, int *cnt_sh /*[256]*/, int *res_sh, int &count_out) {
+    const int tid = threadIdx.x;
+    const int per = (n + 255) / 256;
+    const int lo = tid * per, hi = min(n, lo + per);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += flag(i) ? 1 : 0;
+    __syncthreads();
+    cnt_sh[tid] = c;
+    if (tid == 0) *res_sh = -1;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? cnt_sh[tid - o] : 0;
+        __syncthreads();
+        cnt_sh[tid] += v;
+        __syncthreads();
+    }
+    const int before = tid ? cnt_sh[tid - 1] : 0;
+    count_out = cnt_sh[255];
+    if (r >= before && r < before + c) {
+        int k = r - before;
+        for (int i = lo; i < hi; ++i)
+            if (flag(i)) {
+                if (k == 0) { *res_sh = i; break; }
+                --k;
+            }
+    }
+    __syncthreads();
+    return *res_sh;
+}
+
+// min over tau in (lo, hi] of comp_start(comp, tau); INT_MAX for an empty range
+__device__ inline int block_range_min(const Dims &d, const Work &w, size_t rowoff, int comp, int lo, int hi, int *sh) {
+    int v = 0x7fffffff;
+    for (int tau = lo + 1 + (int)threadIdx.x; tau <= hi; tau += 256) v = min(v, comp_start(d, w, rowoff, comp, tau));
+    return block_min_int(v, sh);
+}
+
+struct MoveSpec { int kind, tgt, slot, scan; };   // slot 0..3 = S->E move, E->I move, S->E occult, E->I occult
+
+// Proposal for one chain by one workgroup; writes ch.mv[b].
+__device__ inline void propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
+                               MoveSpec spec, int nbuf, int *cnt_sh, int *ish) {
+    __shared__ Move mv;
+    __shared__ int res_sh;
+    const int tid = threadIdx.x;
+    const RngKey key = rng_key(s, ch, b);
+    const uint32_t stream = RS_MOVE_BASE + (uint32_t)(spec.scan * 4 + spec.slot);
+    const int tgt = spec.tgt;
+    const int *rowtot = w.rowtot + ((size_t)b * 2 + tgt) * d.Mp;
+    if (tid == 0) {
+        mv.valid = 1; mv.n = 0; mv.tgt = tgt; mv.kind = spec.kind; mv.slot = spec.slot;
+        mv.logq = 0.0; mv.any_dI = 0; mv.LO = d.T; mv.HI = -1;
+        for (int j = 0; j < MMAX; ++j) { mv.tm[j] = mv.tt[j] = mv.tdt[j] = mv.tx[j] = 0; mv.b[j] = -1; }
+        double ua, ub;
+        rng_uniform2(key, stream, 15u, ua, ub);
+        mv.logu = log(ua);
+    }
+    __syncthreads();
+
+    if (spec.kind == 0) {
+        // ---- UncalibratedEventTimesUpdate ---------------------------------
+        int H;
+        (void)block_select(d.M, 0x7fffffff, [&](int m) { return rowtot[m] > 0; }, cnt_sh, &res_sh, H);
+        const int nsel = min(min(s.mmax, MMAX), H);
+        int chosen_pos[MMAX];
+        for (int j = 0; j < nsel; ++j) {
+            double u_m, u_t, u_d, u_x;
+            rng_uniform2(key, stream, (uint32_t)(2 * j), u_m, u_t);
+            rng_uniform2(key, stream, (uint32_t)(2 * j + 1), u_d, u_x);
+            // j-th distinct hot row: position among the remaining hot rows
+            int pos = rng_index(u_m, H - j);
+            for (int a = 0; a < j; ++a) {            // chosen_pos kept ascending
+                if (pos >= chosen_pos[a]) ++pos;
+            }
+            int ins = j;
+            while (ins > 0 && chosen_pos[ins - 1] > pos) { chosen_pos[ins] = chosen_pos[ins - 1]; --ins; }
+            chosen_pos[ins] = pos;
+            int dummy;
+            const int m = block_select(d.M, pos, [&](int mm) { return rowtot[mm] > 0; }, cnt_sh, &res_sh, dummy);
+            const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
+            const int *krow = w.K[tgt] + rowoff;
+            int D;
+            (void)block_select(d.T, 0x7fffffff, [&](int t) { return krow[t] > 0; }, cnt_sh, &res_sh, D);
+            const int t = block_select(d.T, rng_index(u_t, D), [&](int tt) { return krow[tt] > 0; }, cnt_sh, &res_sh,
+                                       dummy);
+            const int v = rng_index(u_d, 2 * s.dmax);
+            const int delta = v < s.dmax ? v - s.dmax : v - s.dmax + 1;
+            const int t2 = t + delta;
+            if (t2 < 0 || t2 >= d.T) {               // out of range: auto-reject (target_log_prob = -inf)
+                if (tid == 0) {
+                    mv.valid = 0;
+                    mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = 0;
+                }
+                __syncthreads();
+                continue;
+            }
+            const int lo = min(t, t2), hi = max(t, t2);
+            const int src = tgt, dst = tgt + 1;
+            // the compartment that LOSES x on (lo,hi]: dest if moved later, source if moved earlier
+            const int dec = delta > 0 ? dst : src, inc = delta > 0 ? src : dst;
+            const bool dec_unbounded = (dec == 0);   // S: prev_event_id None -> no bound
+            const bool inc_unbounded = (inc == 0);
+            const int min_dec = dec_unbounded ? 0x7fffffff : block_range_min(d, w, rowoff, dec, lo, hi, ish);
+            const int min_inc = inc_unbounded ? 0x7fffffff : block_range_min(d, w, rowoff, inc, lo, hi, ish);
+            if (tid == 0) {
+                const int kt = krow[t], kt2 = krow[t2];
+                const int xmax = max(0, min(min(s.nmax, kt), min_dec));
+                const int x = rng_index(u_x, xmax + 1);
+                // reverse move from t2 back to t on the proposed events
+                const int Dn = D - ((x > 0 && x == kt) ? 1 : 0) + ((x > 0 && kt2 == 0) ? 1 : 0);
+                const long long binc = inc_unbounded ? 0x7fffffffLL : (long long)min_inc + x;
+                const int xmax_r = (int)max(0LL, min((long long)min(s.nmax, kt2 + x), binc));
+                mv.logq += (-log((double)Dn) - log((double)(xmax_r + 1))) - (-log((double)D) - log((double)(xmax + 1)));
+                const int i = mv.n++;
+                mv.m[i] = m; mv.a[i] = t; mv.b[i] = t2; mv.dka[i] = -x; mv.dkb[i] = x;
+                mv.lo[i] = lo; mv.hi[i] = hi;
+                mv.dsrc[i] = delta > 0 ? x : -x;     // moved later: source keeps x longer
+                mv.LO = min(mv.LO, lo); mv.HI = max(mv.HI, hi);
+                if (tgt == 1 && x != 0) mv.any_dI = 1;
+                mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = x;
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- UncalibratedOccultUpdate --------------------------------------
+        const int R = s.tr_hi - s.tr_lo;
+        double u_br, u_m, u_t, u_x;
+        rng_uniform2(key, stream, 0u, u_br, u_m);
+        rng_uniform2(key, stream, 1u, u_t, u_x);
+        auto range_tot = [&](int m) {
+            const int *kr = w.K[tgt] + ((size_t)b * d.Mp + m) * d.Tp;
+            int sum = 0;
+            for (int t = s.tr_lo; t < s.tr_hi; ++t) sum += kr[t];
+            return sum;
+        };
+        int Hd;
+        (void)block_select(d.M, 0x7fffffff, [&](int m) { return range_tot(m) > 0; }, cnt_sh, &res_sh, Hd);
+        const bool is_del = (u_br < 0.5) && Hd > 0;
+        const int src = tgt, dst = tgt + 1;
+        int m, t, dummy;
+        if (!is_del) {
+            m = rng_index(u_m, d.M);
+            t = s.tr_lo + rng_index(u_t, R);
+        } else {
+            m = block_select(d.M, rng_index(u_m, Hd), [&](int mm) { return range_tot(mm) > 0; }, cnt_sh, &res_sh, dummy);
+        }
+        const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
+        const int *krow = w.K[tgt] + rowoff;
+        int Dm;                                       // hot days of row m inside the range
+        (void)block_select(R, 0x7fffffff, [&](int i) { return krow[s.tr_lo + i] > 0; }, cnt_sh, &res_sh, Dm);
+        if (is_del)
+            t = s.tr_lo + block_select(R, rng_index(u_t, Dm), [&](int i) { return krow[s.tr_lo + i] > 0; }, cnt_sh,
+                                       &res_sh, dummy);
+        const int rt_m = range_tot(m);
+        const int min_src = src == 0 ? 0x7fffffff : block_range_min(d, w, rowoff, src, t, d.T, ish);
+        const int min_dst = block_range_min(d, w, rowoff, dst, t, d.T, ish);
+        if (tid == 0) {
+            const int kt = krow[t];
+            const double lM = log((double)d.M), lR = log((double)R), l2 = 0.6931471805599453;
+            int x;
+            if (!is_del) {
+                const int xmax = max(0, min(s.occult_nmax, min_src));
+                x = rng_index(u_x, xmax + 1);
+                const double qf = (Hd > 0 ? -l2 : 0.0) - lM - lR - log((double)(xmax + 1));
+                const int Hd2 = Hd + ((rt_m == 0 && x > 0) ? 1 : 0);
+                const int Dm2 = Dm + ((kt == 0 && x > 0) ? 1 : 0);
+                const long long bd = (long long)min_dst + x;
+                const int xmax_r = (int)max(0LL, min((long long)min(s.occult_nmax, kt + x), bd));
+                const double qr = (Hd2 > 0 && kt + x > 0)
+                                      ? -l2 - log((double)Hd2) - log((double)Dm2) - log((double)(xmax_r + 1))
+                                      : -INFINITY;
+                mv.logq = qr - qf;
+                mv.dka[0] = x; mv.dsrc[0] = -x;
+            } else {
+                const int xmax = max(0, min(min(s.occult_nmax, kt), min_dst));
+                x = rng_index(u_x, xmax + 1);
+                const double qf = -l2 - log((double)Hd) - log((double)Dm) - log((double)(xmax + 1));
+                const int Hd2 = Hd - ((x > 0 && rt_m == x) ? 1 : 0);
+                const long long bs = src == 0 ? 0x7fffffffLL : (long long)min_src + x;
+                const int xmax_r = (int)max(0LL, min((long long)s.occult_nmax, bs));
+                const double qr = (Hd2 > 0 ? -l2 : 0.0) - lM - lR - log((double)(xmax_r + 1));
+                mv.logq = qr - qf;
+                mv.dka[0] = -x; mv.dsrc[0] = x;
+            }
+            mv.n = 1;
+            mv.m[0] = m; mv.a[0] = t; mv.b[0] = -1; mv.dkb[0] = 0;
+            mv.lo[0] = t; mv.hi[0] = d.T - 1;
+            mv.LO = t; mv.HI = d.T - 1;
+            mv.any_dI = (tgt == 1 && x != 0) ? 1 : 0;
+            mv.tm[0] = m; mv.tt[0] = t; mv.tdt[0] = is_del ? -1 : 1; mv.tx[0] = x;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) ch.mv[(size_t)nbuf * s.B + b] = mv;
+}
+
+// Per-cell log-likelihood pieces: th = parameter dependent (S->E and I->R
+// rates), cn = parameter free (binomial coefficients + E->I term).
+__device__ inline void cell_terms(const Dims &d, double S, double E, double I, double kse, double kei, double kir,
+                                  double F, double ee, double psiW, double r_ir, double L_ei, double r_ei,
+                                  double &th, double &cn) {
+    cn = lbinom(S, kse) + lbinom(E, kei) + lbinom(I, kir) + kei * L_ei - (E - kei) * r_ei;
+    const double rr = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
+    th = (kse != 0.0 ? kse * log1mexp(rr) : 0.0) - (S - kse) * rr;
+    th += (kir != 0.0 ? kir * log1mexp(r_ir) : 0.0) - (I - kir) * r_ir;
+}
+
+// k_move_delta: log-likelihood change of the pending proposal, over the cells it touches.
+// grid (nrb_d, B); wave = one row at a time, lanes over the days of the hull.
+__global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf) {
+    __shared__ Move mv;
+    __shared__ double sh_th[4], sh_cn[4];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) mv = ch.mv[(size_t)buf * s.B + b];
+    __syncthreads();
+    double dth = 0.0, dcn = 0.0;
+    if (mv.valid && mv.n > 0) {
+        const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
+        const double r_ei = d.nu * d.dt, L_ei = log1mexp(r_ei);
+        const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
+        const int r_lo = blockIdx.x * rows_per_blk, r_hi = min(d.M, r_lo + rows_per_blk);
+        for (int j = r_lo + wave; j < r_hi; j += 4) {
+            bool mine = false;
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == j);
+            if (!mine && !mv.any_dI) continue;       // wave-uniform
+            const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
+            const double eb = w.eb[(size_t)b * d.Mp + j];
+            double coef[MMAX];
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)          // Cstar is symmetric: read row m_i contiguously
+                coef[i] = (i < mv.n && mv.tgt == 1)
+                              ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                              : 0.0;
+            for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
+                int dS = 0, dE = 0, dI = 0, dkt = 0;
+                double dF = 0.0;
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i) {
+                    if (i >= mv.n) break;
+                    const bool in_state = t > mv.lo[i] && t <= mv.hi[i];
+                    if (in_state) dF += coef[i];
+                    if (mv.m[i] != j) continue;
+                    if (in_state) {
+                        if (mv.tgt == 0) { dS += mv.dsrc[i]; dE -= mv.dsrc[i]; }
+                        else { dE += mv.dsrc[i]; dI -= mv.dsrc[i]; }
+                    }
+                    if (t == mv.a[i]) dkt += mv.dka[i];
+                    if (t == mv.b[i]) dkt += mv.dkb[i];
+                }
+                if (dS == 0 && dE == 0 && dI == 0 && dkt == 0 && dF == 0.0) continue;
+                const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
+                const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
+                const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
+                const double F = w.F[rowoff + t];
+                const double ee = w.ea[(size_t)b * d.Tp + t] * eb, psiW = psi * c.W[t];
+                const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
+                if (mine) {
+                    double th0, cn0, th1, cn1;
+                    cell_terms(d, S, E, I, kse, kei, kir, F, ee, psiW, r_ir, L_ei, r_ei, th0, cn0);
+                    cell_terms(d, S + dS, E + dE, I + dI, kse + dk0, kei + dk1, kir, F + dF, ee, psiW, r_ir,
+                               L_ei, r_ei, th1, cn1);
+                    dth += th1 - th0;
+                    dcn += cn1 - cn0;
+                } else {
+                    const double r0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
+                    const double r1 = (ee * (I + psiW * (F + dF)) + d.rate_floor) * d.dt;
+                    dth += (kse != 0.0 ? kse * (log1mexp(r1) - log1mexp(r0)) : 0.0) - (S - kse) * (r1 - r0);
+                }
+            }
+        }
+    }
+    dth = wave_sum(dth);
+    dcn = wave_sum(dcn);
+    if (lane == 0) { sh_th[wave] = dth; sh_cn[wave] = dcn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *out = ch.Dpart + ((size_t)b * s.nrb_d + blockIdx.x) * 2;
+        out[0] = sh_th[0] + sh_th[1] + sh_th[2] + sh_th[3];
+        out[1] = sh_cn[0] + sh_cn[1] + sh_cn[2] + sh_cn[3];
+    }
+}
+
+// k_move_pa: (1) finalize the pending proposal -- MetropolisHastings accept
+// test (mcmc_kernel_factory.py:72,99), F column update by every block, row-local
+// state update and trace by block 0 -- then (2) block 0 draws the next proposal.
+// next.kind < 0: finalize only.  grid (nrb_d, B).  The pending descriptor is read from
+// buffer pbuf, the next one written to pbuf^1 (late blocks must not see the new one).
+__global__ __launch_bounds__(256) void k_move_pa(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
+                                                 int have_prev, int pbuf) {
+    __shared__ Move mv;
+    __shared__ int cnt_sh[256];
+    __shared__ int ish[4];
+    __shared__ int s_acc;
+    __shared__ double s_dth, s_dcn;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (have_prev) {
+        if (tid == 0) {
+            mv = ch.mv[(size_t)pbuf * s.B + b];
+            double dth = 0.0, dcn = 0.0;
+            for (int i = 0; i < s.nrb_d; ++i) {
+                dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
+                dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
+            }
+            const double ratio = dth + dcn + mv.logq;
+            s_acc = (mv.valid && mv.logu < ratio) ? 1 : 0;   // NaN -> reject
+            s_dth = dth; s_dcn = dcn;
+        }
+        __syncthreads();
+        if (s_acc && mv.any_dI) {
+            // F[j][t] += sum_i Cstar[j][m_i] dI_i / N_{m_i}  on each update's day window
+            const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
+            const int r_lo = blockIdx.x * rows_per_blk, r_hi = min(d.M, r_lo + rows_per_blk);
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int j = r_lo + wave; j < r_hi; j += 4) {
+                double coef[MMAX];
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                                       : 0.0;
+                double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
+                for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
+                    double dF = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MMAX; ++i)
+                        if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+                    if (dF != 0.0) Fr[t] += dF;
+                }
+            }
+        }
+        if (blockIdx.x == 0) {
+            if (s_acc) {
+                for (int i = 0; i < mv.n; ++i) {
+                    const size_t rowoff = ((size_t)b * d.Mp + mv.m[i]) * d.Tp;
+                    const int src = mv.tgt, dst = mv.tgt + 1;
+                    for (int t = mv.lo[i] + 1 + tid; t <= mv.hi[i]; t += 256) {
+                        w.St[src][rowoff + t] += mv.dsrc[i];
+                        w.St[dst][rowoff + t] -= mv.dsrc[i];
+                        if (mv.tgt == 1) w.Dir[(size_t)b * d.Tp + t] -= (double)mv.dsrc[i];
+                    }
+                    if (tid == 0) {
+                        w.K[mv.tgt][rowoff + mv.a[i]] += mv.dka[i];
+                        if (mv.b[i] >= 0) w.K[mv.tgt][rowoff + mv.b[i]] += mv.dkb[i];
+                        w.rowtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += mv.dka[i] + mv.dkb[i];
+                    }
+                    __syncthreads();     // two updates may touch the same Dir[t]
+                }
+            }
+            if (tid == 0) {
+                double *hs = ch.hs + (size_t)b * NHS;
+                if (s_acc) { hs[HS_LP_THETA] += s_dth; hs[HS_LP_CONST] += s_dcn; }
+                const unsigned slot = ch.sweep[b] - ch.slot0[0];
+                if (slot < (unsigned)s.cap) {
+                    double *tr = ch.tr_mv + (((size_t)slot * s.B + b) * 4 + mv.slot) * NMVTR;
+                    tr[0] = (double)s_acc;
+                    tr[1] = hs[HS_LP_THETA] + hs[HS_LP_CONST];
+                    for (int j = 0; j < MMAX; ++j) {
+                        tr[2 + j] = mv.tm[j]; tr[2 + MMAX + j] = mv.tt[j];
+                        tr[2 + 2 * MMAX + j] = mv.tdt[j]; tr[2 + 3 * MMAX + j] = mv.tx[j];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x == 0 && next.kind >= 0) propose(d, w, s, ch, b, next, pbuf ^ 1, cnt_sh, ish);
+}
+
+// End of sweep: record the event tensor in the reference's [M][T][3] order and
+// advance the sweep counter.  grid (blocks, B).
+__global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Chains ch) {
+    const int b = blockIdx.y;
+    const unsigned slot = ch.sweep[b] - ch.slot0[0];
+    if (slot < (unsigned)s.cap) {
+        int *out = ch.tr_events + ((size_t)slot * s.B + b) * d.M * d.T * 3;
+        const size_t n = (size_t)d.M * d.T;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+            const int t = (int)(i % d.T), m = (int)(i / d.T);
+            const size_t q = ((size_t)b * d.Mp + m) * d.Tp + t;
+            out[i * 3 + 0] = w.K[0][q];
+            out[i * 3 + 1] = w.K[1][q];
+            out[i * 3 + 2] = w.K[2][q];
+        }
+    }
+}
+
+__global__ void k_advance(Chains ch, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) ch.sweep[b] += 1;
+}
+
+}  // namespace seir

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/seir_hip.h"
-#include "logprob_kernels.h"
+#include "sampler_kernels.h"
 
 using namespace seir;
 
@@ -95,8 +95,10 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
     d.Tp = ceil_to(T, 64);
     d.Kp = ceil_to(M, 4);
     d.P = 6 + (T - 1) + M;
+    d.Pp = d.P;
     d.nrb_scan = (M + SCAN_ROWS - 1) / SCAN_ROWS;
-    d.nrb_se = (M + SE_ROWS - 1) / SE_ROWS;
+    d.nmt = d.Mp / SE_TM;
+    d.ntc = d.Tp / 64;
     d.nu = ds->nu; d.dt = ds->time_delta; d.rate_floor = ds->rate_floor;
     d.car_half_logdet = ds->car_half_logdet;
     ctx->Bmax = B;
@@ -162,10 +164,13 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
     if ((rc = dev_alloc(ctx, &w.rir, (size_t)B * d.Tp))) return rc;
     if ((rc = dev_alloc(ctx, &w.scal, (size_t)B * NSCAL))) return rc;
     if ((rc = dev_alloc(ctx, &w.Qs, (size_t)B * d.Mp))) return rc;
-    if ((rc = dev_alloc(ctx, &w.Lpart, (size_t)B * d.nrb_se))) return rc;
-    if ((rc = dev_alloc(ctx, &w.Ppart, (size_t)B * d.nrb_se))) return rc;
-    if ((rc = dev_alloc(ctx, &w.Kpart, (size_t)B * d.nrb_se * d.Tp))) return rc;
-    if ((rc = dev_alloc(ctx, &w.Rsum, (size_t)B * d.Mp))) return rc;
+    if ((rc = dev_alloc(ctx, &w.Kir, (size_t)B * d.Tp))) return rc;
+    if ((rc = dev_alloc(ctx, &w.Dir, (size_t)B * d.Tp))) return rc;
+    if ((rc = dev_alloc(ctx, &w.constsum, (size_t)B))) return rc;
+    if ((rc = dev_alloc(ctx, &w.Lpart, (size_t)B * d.nmt * d.ntc))) return rc;
+    if ((rc = dev_alloc(ctx, &w.Ppart, (size_t)B * d.nmt * d.ntc))) return rc;
+    if ((rc = dev_alloc(ctx, &w.Kpart, (size_t)B * d.nmt * d.Tp))) return rc;
+    if ((rc = dev_alloc(ctx, &w.Rpart, (size_t)B * d.ntc * d.Mp))) return rc;
 
     if ((rc = dev_alloc(ctx, &ctx->u_stage, (size_t)B * d.P))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->ev_stage, (size_t)B * M * T * 3))) return rc;
@@ -204,10 +209,14 @@ static int check_batch(seir_ctx *ctx, int B) {
 }
 
 // --- individual launches ---------------------------------------------------
+template <int SRC>
 static void launch_scan(seir_ctx *ctx, int B, const double *events) {
     const Dims &d = ctx->d;
-    hipLaunchKernelGGL(k_scan, dim3(d.nrb_scan, B), dim3(256), (size_t)4 * d.Tp * 2 * sizeof(double),
+    hipLaunchKernelGGL(k_scan<SRC>, dim3(d.nrb_scan, B), dim3(256), (size_t)4 * d.Tp * 2 * sizeof(double),
                        ctx->stream, d, ctx->c, ctx->w, events);
+}
+static void launch_colreduce(seir_ctx *ctx, int B) {
+    hipLaunchKernelGGL(k_colreduce, dim3(B), dim3(256), 0, ctx->stream, ctx->d, ctx->w);
 }
 static void launch_gemm(seir_ctx *ctx, int B) {
     const Dims &d = ctx->d;
@@ -218,20 +227,22 @@ static void launch_gemm(seir_ctx *ctx, int B) {
 static void launch_params(seir_ctx *ctx, int B, const double *u) {
     hipLaunchKernelGGL(k_params, dim3(B), dim3(256), 0, ctx->stream, ctx->d, ctx->c, ctx->w, u);
 }
+template <int SRC>
 static void launch_se(seir_ctx *ctx, int B, bool grad) {
     const Dims &d = ctx->d;
+    const dim3 grid(d.ntc, d.nmt, B);
     if (grad)
-        hipLaunchKernelGGL(k_se<true>, dim3(d.nrb_se, B), dim3(256), (size_t)4 * d.Tp * sizeof(double),
-                           ctx->stream, d, ctx->c, ctx->w);
+        hipLaunchKernelGGL((k_se<true, SRC>), grid, dim3(256), 0, ctx->stream, d, ctx->c, ctx->w);
     else
-        hipLaunchKernelGGL(k_se<false>, dim3(d.nrb_se, B), dim3(256), 0, ctx->stream, d, ctx->c, ctx->w);
+        hipLaunchKernelGGL((k_se<false, SRC>), grid, dim3(256), 0, ctx->stream, d, ctx->c, ctx->w);
 }
 static void launch_finish(seir_ctx *ctx, int B, const double *u, double *logp, double *grad) {
+    const size_t lds = (size_t)ctx->d.Tp * sizeof(double);
     if (grad)
-        hipLaunchKernelGGL(k_finish<true>, dim3(B), dim3(256), 0, ctx->stream, ctx->d, ctx->c, ctx->w, u, logp,
+        hipLaunchKernelGGL(k_finish<true>, dim3(B), dim3(256), lds, ctx->stream, ctx->d, ctx->c, ctx->w, u, logp,
                            grad);
     else
-        hipLaunchKernelGGL(k_finish<false>, dim3(B), dim3(256), 0, ctx->stream, ctx->d, ctx->c, ctx->w, u, logp,
+        hipLaunchKernelGGL(k_finish<false>, dim3(B), dim3(256), lds, ctx->stream, ctx->d, ctx->c, ctx->w, u, logp,
                            grad);
 }
 
@@ -239,7 +250,8 @@ extern "C" int seir_prepare_events_dev(seir_ctx *ctx, int32_t B, const double *e
     int rc = check_batch(ctx, B);
     if (rc) return rc;
     if (!events_dev) return fail(SEIR_ERR_INVALID, "null events pointer");
-    launch_scan(ctx, B, events_dev);
+    launch_scan<0>(ctx, B, events_dev);
+    launch_colreduce(ctx, B);
     launch_gemm(ctx, B);
     HIP_TRY(hipGetLastError());
     ctx->last_events = events_dev;
@@ -254,7 +266,7 @@ extern "C" int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_
     if (!ctx->prepared) return fail(SEIR_ERR_STATE, "seir_prepare_events_dev has not been called");
     if (!u_dev || !logp_dev) return fail(SEIR_ERR_INVALID, "null u/logp pointer");
     launch_params(ctx, B, u_dev);
-    launch_se(ctx, B, grad_dev != nullptr);
+    launch_se<0>(ctx, B, grad_dev != nullptr);
     launch_finish(ctx, B, u_dev, logp_dev, grad_dev);
     HIP_TRY(hipGetLastError());
     ctx->last_u = u_dev; ctx->last_logp = logp_dev; ctx->last_grad = grad_dev;
@@ -344,10 +356,10 @@ extern "C" int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t
         return fail(SEIR_ERR_STATE, "last evaluation had no gradient buffer");
     auto once = [&]() {
         switch (which) {
-            case SEIR_K_SCAN: launch_scan(ctx, B, ctx->last_events); break;
+            case SEIR_K_SCAN: launch_scan<0>(ctx, B, ctx->last_events); break;
             case SEIR_K_GEMM: launch_gemm(ctx, B); break;
-            case SEIR_K_SE_VALUE: launch_se(ctx, B, false); break;
-            case SEIR_K_SE_GRAD: launch_se(ctx, B, true); break;
+            case SEIR_K_SE_VALUE: launch_se<0>(ctx, B, false); break;
+            case SEIR_K_SE_GRAD: launch_se<0>(ctx, B, true); break;
             default: launch_finish(ctx, B, ctx->last_u, ctx->last_logp, ctx->last_grad); break;
         }
     };
@@ -361,5 +373,365 @@ extern "C" int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     HIP_TRY(hipGetLastError());
     *mean_ms = ms / iters;
+    return 0;
+}
+
+// ===========================================================================
+// Sampler (see include/seir_hip.h, "Device-resident Metropolis-within-Gibbs")
+// ===========================================================================
+struct seir_sampler {
+    seir_ctx *ctx = nullptr;
+    SamplerCfg cfg{};
+    Chains ch{};
+    int record_events = 1;
+    std::vector<void *> allocs;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool use_graph = true;
+    bool have_state = false;
+    double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
+};
+
+template <typename T>
+static int s_alloc(seir_sampler *s, T **p, size_t count) {
+    void *q = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&q, bytes));
+    s->allocs.push_back(q);
+    HIP_TRY(hipMemset(q, 0, bytes));
+    *p = (T *)q;
+    return 0;
+}
+
+static void drop_graph(seir_sampler *s) {
+    if (s->gexec) { (void)hipGraphExecDestroy(s->gexec); s->gexec = nullptr; }
+    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+}
+
+extern "C" void seir_sampler_destroy(seir_sampler *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    drop_graph(s);
+    for (void *p : s->allocs) (void)hipFree(p);
+    Work &w = s->ctx->w;
+    for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
+    w.rowtot = nullptr;
+    delete s;
+}
+
+extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, seir_sampler **out) {
+    if (!ctx || !ds || !out) return fail(SEIR_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const Dims &d = ctx->d;
+    const int B = ds->num_chains;
+    if (B < 1 || B > ctx->Bmax) return fail(SEIR_ERR_INVALID, "num_chains=%d outside [1, %d]", B, ctx->Bmax);
+    if (ctx->w.K[0]) return fail(SEIR_ERR_STATE, "this context already has a sampler");
+    if (ds->m < 1 || ds->m > MMAX) return fail(SEIR_ERR_INVALID, "m=%d outside [1, %d]", ds->m, MMAX);
+    if (ds->dmax < 1 || ds->nmax < 0 || ds->occult_nmax < 0 || ds->num_event_time_updates < 0)
+        return fail(SEIR_ERR_INVALID, "bad dmax/nmax/occult_nmax/num_event_time_updates");
+    if (ds->t_range_lo < 0 || ds->t_range_hi > d.T || ds->t_range_lo >= ds->t_range_hi)
+        return fail(SEIR_ERR_INVALID, "occult t_range [%d,%d) outside [0,%d)", ds->t_range_lo, ds->t_range_hi, d.T);
+    if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
+    if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    seir_sampler *s = new (std::nothrow) seir_sampler();
+    if (!s) return fail(SEIR_ERR_DEVICE, "out of host memory");
+    s->ctx = ctx;
+    SamplerCfg &c = s->cfg;
+    c.B = B; c.dmax = ds->dmax; c.nmax = ds->nmax; c.mmax = ds->m; c.occult_nmax = ds->occult_nmax;
+    c.n_scans = ds->num_event_time_updates; c.tr_lo = ds->t_range_lo; c.tr_hi = ds->t_range_hi;
+    c.L = ds->num_leapfrog_steps;
+    c.k0 = (uint32_t)(ds->seed & 0xffffffffu); c.k1 = (uint32_t)(ds->seed >> 32);
+    c.chain0 = ds->first_chain_id;
+    c.adapt_step = 0; c.adapt_mass = 0; c.n_adapt = 0; c.target_accept = 0.75;
+    c.cap = ds->trace_capacity;
+    c.nrb_d = (d.M + 7) / 8;
+    s->record_events = ds->record_events;
+    s->use_graph = getenv("SEIR_NO_GRAPH") == nullptr;
+
+    int rc = 0;
+    Work &w = ctx->w;
+    const size_t cells = (size_t)ctx->Bmax * d.Mp * d.Tp;
+    Chains &ch = s->ch;
+#define S_ALLOC(ptr, n) if (!rc) rc = s_alloc(s, &(ptr), (n))
+    for (int x = 0; x < 3; ++x) { S_ALLOC(w.K[x], cells); S_ALLOC(w.St[x], cells); }
+    S_ALLOC(w.rowtot, (size_t)ctx->Bmax * 2 * d.Mp);
+    S_ALLOC(ch.q, (size_t)B * d.Pp); S_ALLOC(ch.p, (size_t)B * d.Pp); S_ALLOC(ch.q0, (size_t)B * d.Pp);
+    S_ALLOC(ch.grad, (size_t)B * d.Pp); S_ALLOC(ch.var, (size_t)B * d.Pp);
+    S_ALLOC(ch.rv_mean, (size_t)B * d.Pp); S_ALLOC(ch.rv_m2, (size_t)B * d.Pp);
+    S_ALLOC(ch.hs, (size_t)B * NHS);
+    S_ALLOC(ch.mv, (size_t)2 * B);
+    S_ALLOC(ch.Dpart, (size_t)B * c.nrb_d * 2);
+    S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
+    S_ALLOC(ch.tr_theta, (size_t)c.cap * B * d.P);
+    S_ALLOC(ch.tr_events, s->record_events ? (size_t)c.cap * B * d.M * d.T * 3 : 1);
+    S_ALLOC(ch.tr_hmc, (size_t)c.cap * B * 3);
+    S_ALLOC(ch.tr_mv, (size_t)c.cap * B * 4 * NMVTR);
+    S_ALLOC(s->ev_stage, (size_t)B * d.M * d.T * 3);
+#undef S_ALLOC
+    if (!rc) {
+        std::vector<double> ones((size_t)B * d.Pp, 1.0), hs((size_t)B * NHS, 0.0);
+        for (int b = 0; b < B; ++b) hs[(size_t)b * NHS + HS_EPS] = 0.1;     // inference.py:325
+        hipError_t e = hipMemcpy(ch.var, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ch.hs, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(SEIR_ERR_DEVICE, "sampler init copy failed: %s", hipGetErrorString(e));
+    }
+    if (rc) { seir_sampler_destroy(s); return rc; }
+    *out = s;
+    return 0;
+}
+
+static int sampler_check(seir_sampler *s) {
+    if (!s) return fail(SEIR_ERR_INVALID, "null sampler");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    return 0;
+}
+
+static void enqueue_refresh(seir_sampler *s) {
+    seir_ctx *ctx = s->ctx;
+    const Dims &d = ctx->d;
+    const int B = s->cfg.B;
+    launch_scan<1>(ctx, B, nullptr);
+    launch_colreduce(ctx, B);
+    launch_gemm(ctx, B);
+    hipLaunchKernelGGL(k_chain_tables, dim3(B), dim3(256), 0, ctx->stream, d, ctx->c, ctx->w, s->ch);
+    launch_se<1>(ctx, B, false);
+    hipLaunchKernelGGL(k_chain_refresh, dim3(B), dim3(256), (size_t)d.Tp * sizeof(double), ctx->stream, d, ctx->c,
+                       ctx->w, s->ch);
+}
+
+extern "C" int seir_sampler_refresh(seir_sampler *s) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
+    enqueue_refresh(s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int seir_sampler_set_state(seir_sampler *s, const double *u, const double *events) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (!u || !events) return fail(SEIR_ERR_INVALID, "null pointer");
+    seir_ctx *ctx = s->ctx;
+    const Dims &d = ctx->d;
+    const int B = s->cfg.B;
+    for (size_t i = 0, n = (size_t)B * d.M * d.T * 3; i < n; ++i)
+        if (!(events[i] >= 0.0 && events[i] < 2147483648.0 && events[i] == std::floor(events[i])))
+            return fail(SEIR_ERR_INVALID, "events[%zu]=%g is not a non-negative integer count", i, events[i]);
+    HIP_TRY(hipMemcpyAsync(s->ch.q, u, sizeof(double) * B * d.P, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(s->ev_stage, events, sizeof(double) * B * d.M * d.T * 3, hipMemcpyHostToDevice,
+                           ctx->stream));
+    hipLaunchKernelGGL(k_import_events, dim3(1024), dim3(256), 0, ctx->stream, d, ctx->w, s->ev_stage, B);
+    s->have_state = true;
+    enqueue_refresh(s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int seir_sampler_get_state(seir_sampler *s, double *u, double *events, double *logp) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
+    seir_ctx *ctx = s->ctx;
+    const Dims &d = ctx->d;
+    const int B = s->cfg.B;
+    if (u) HIP_TRY(hipMemcpyAsync(u, s->ch.q, sizeof(double) * B * d.P, hipMemcpyDeviceToHost, ctx->stream));
+    if (events) {
+        hipLaunchKernelGGL(k_export_events, dim3(1024), dim3(256), 0, ctx->stream, d, ctx->w, s->ev_stage, B);
+        HIP_TRY(hipMemcpyAsync(events, s->ev_stage, sizeof(double) * B * d.M * d.T * 3, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    }
+    std::vector<double> hs;
+    if (logp) {
+        hs.resize((size_t)B * NHS);
+        HIP_TRY(hipMemcpyAsync(hs.data(), s->ch.hs, sizeof(double) * B * NHS, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (logp)
+        for (int b = 0; b < B; ++b) logp[b] = hs[(size_t)b * NHS + HS_LP_THETA] + hs[(size_t)b * NHS + HS_LP_CONST];
+    return 0;
+}
+
+static int hs_update(seir_sampler *s, const std::vector<std::pair<int, const double *>> &cols) {
+    const int B = s->cfg.B;
+    std::vector<double> hs((size_t)B * NHS);
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    HIP_TRY(hipMemcpy(hs.data(), s->ch.hs, sizeof(double) * B * NHS, hipMemcpyDeviceToHost));
+    for (auto &c : cols)
+        for (int b = 0; b < B; ++b) hs[(size_t)b * NHS + c.first] = c.second[b];
+    HIP_TRY(hipMemcpy(s->ch.hs, hs.data(), sizeof(double) * B * NHS, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int seir_sampler_set_kernel(seir_sampler *s, const double *step_size, const double *variance) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    const Dims &d = s->ctx->d;
+    const int B = s->cfg.B;
+    if (step_size) {
+        for (int b = 0; b < B; ++b)
+            if (!(step_size[b] > 0.0)) return fail(SEIR_ERR_INVALID, "step_size[%d] must be positive", b);
+        if ((rc = hs_update(s, {{HS_EPS, step_size}}))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    if (variance) {
+        for (size_t i = 0; i < (size_t)B * d.P; ++i)
+            if (!(variance[i] > 0.0)) return fail(SEIR_ERR_INVALID, "variance[%zu] must be positive", i);
+        HIP_TRY(hipMemcpy(s->ch.var, variance, sizeof(double) * B * d.P, hipMemcpyHostToDevice));
+    } else {
+        std::vector<double> ones((size_t)B * d.P, 1.0);
+        HIP_TRY(hipMemcpy(s->ch.var, ones.data(), sizeof(double) * B * d.P, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int seir_sampler_get_kernel(seir_sampler *s, double *step_size, double *variance) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    const Dims &d = s->ctx->d;
+    const int B = s->cfg.B;
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    if (step_size) {
+        std::vector<double> hs((size_t)B * NHS);
+        HIP_TRY(hipMemcpy(hs.data(), s->ch.hs, sizeof(double) * B * NHS, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) step_size[b] = hs[(size_t)b * NHS + HS_EPS];
+    }
+    if (variance) HIP_TRY(hipMemcpy(variance, s->ch.var, sizeof(double) * B * d.P, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int seir_sampler_set_adaptation(seir_sampler *s, int32_t adapt_step, int32_t adapt_mass, int32_t n_adapt,
+                                           double target, const double *rv_count, const double *rv_mean,
+                                           const double *rv_var) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    const Dims &d = s->ctx->d;
+    const int B = s->cfg.B;
+    if (adapt_mass && (!rv_count || !rv_mean || !rv_var))
+        return fail(SEIR_ERR_INVALID, "adapt_mass needs the initial running variance");
+    if (adapt_step && !(target > 0.0 && target < 1.0)) return fail(SEIR_ERR_INVALID, "target_accept_prob in (0,1)");
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    std::vector<double> hs((size_t)B * NHS);
+    HIP_TRY(hipMemcpy(hs.data(), s->ch.hs, sizeof(double) * B * NHS, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+        double *h = hs.data() + (size_t)b * NHS;
+        // a fresh DualAveragingStepSizeAdaptation: error_sum 0, step 0, log_averaging_step 0,
+        // shrinkage target log(10 * current step size)
+        h[HS_DA_ERR] = 0.0; h[HS_DA_STEP] = 0.0; h[HS_DA_LOGAVG] = 0.0;
+        h[HS_DA_MU] = std::log(10.0 * h[HS_EPS]);
+        if (adapt_mass) h[HS_RV_N] = rv_count[b];
+    }
+    HIP_TRY(hipMemcpy(s->ch.hs, hs.data(), sizeof(double) * B * NHS, hipMemcpyHostToDevice));
+    if (adapt_mass) {
+        std::vector<double> m2((size_t)B * d.P);
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < d.P; ++i) {
+                const double v = rv_var[(size_t)b * d.P + i];
+                if (!(v > 0.0)) return fail(SEIR_ERR_INVALID, "running variance must be positive");
+                m2[(size_t)b * d.P + i] = v * rv_count[b];
+            }
+        HIP_TRY(hipMemcpy(s->ch.rv_mean, rv_mean, sizeof(double) * B * d.P, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->ch.rv_m2, m2.data(), sizeof(double) * B * d.P, hipMemcpyHostToDevice));
+        // momentum distribution at bootstrap: the initial running variance
+        HIP_TRY(hipMemcpy(s->ch.var, rv_var, sizeof(double) * B * d.P, hipMemcpyHostToDevice));
+    }
+    SamplerCfg &c = s->cfg;
+    if (c.adapt_step != adapt_step || c.adapt_mass != adapt_mass || c.n_adapt != n_adapt ||
+        c.target_accept != target)
+        drop_graph(s);                               // kernel arguments are baked into the graph
+    c.adapt_step = adapt_step; c.adapt_mass = adapt_mass; c.n_adapt = n_adapt; c.target_accept = target;
+    return 0;
+}
+
+extern "C" int seir_sampler_reset_trace(seir_sampler *s) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    // slot0 = sweep counter of chain 0 (all chains advance together)
+    HIP_TRY(hipMemcpyAsync(s->ch.slot0, s->ch.sweep, sizeof(unsigned), hipMemcpyDeviceToDevice, s->ctx->stream));
+    return 0;
+}
+
+static void enqueue_sweep(seir_sampler *s) {
+    seir_ctx *ctx = s->ctx;
+    const Dims &d = ctx->d;
+    const SamplerCfg &c = s->cfg;
+    const int B = c.B;
+    hipStream_t st = ctx->stream;
+    const size_t lds = (size_t)d.Tp * sizeof(double);
+    // [part 0] HMC on u | events: L+1 gradient evaluations
+    launch_se<1>(ctx, B, true);
+    hipLaunchKernelGGL(k_hmc_step<0>, dim3(B), dim3(256), lds, st, d, ctx->c, ctx->w, c, s->ch);
+    for (int l = 1; l < c.L; ++l) {
+        launch_se<1>(ctx, B, true);
+        hipLaunchKernelGGL(k_hmc_step<1>, dim3(B), dim3(256), lds, st, d, ctx->c, ctx->w, c, s->ch);
+    }
+    launch_se<1>(ctx, B, true);
+    hipLaunchKernelGGL(k_hmc_step<2>, dim3(B), dim3(256), lds, st, d, ctx->c, ctx->w, c, s->ch);
+    // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I])
+    const dim3 gm(c.nrb_d, B);
+    int have_prev = 0, pbuf = 0;
+    for (int scan = 0; scan < c.n_scans; ++scan)
+        for (int slot = 0; slot < 4; ++slot) {
+            const MoveSpec spec{slot >= 2 ? 1 : 0, slot & 1, slot, scan};
+            hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, spec, have_prev, pbuf);
+            pbuf ^= 1;
+            hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf);
+            have_prev = 1;
+        }
+    if (have_prev) {
+        const MoveSpec none{-1, 0, 0, 0};
+        hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+    }
+    if (s->record_events) hipLaunchKernelGGL(k_record, dim3(32, B), dim3(256), 0, st, d, ctx->w, c, s->ch);
+    hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, st, s->ch, B);
+}
+
+extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
+    if (n < 0) return fail(SEIR_ERR_INVALID, "num_sweeps must be >= 0");
+    hipStream_t st = s->ctx->stream;
+    if (s->use_graph && !s->gexec) {
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        enqueue_sweep(s);
+        HIP_TRY(hipStreamEndCapture(st, &s->graph));
+        HIP_TRY(hipGraphInstantiate(&s->gexec, s->graph, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < n; ++i) {
+        if (s->use_graph) HIP_TRY(hipGraphLaunch(s->gexec, st));
+        else enqueue_sweep(s);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, double *theta,
+                                       int32_t *events, double *hmc, double *moves) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    const Dims &d = s->ctx->d;
+    const SamplerCfg &c = s->cfg;
+    if (first < 0 || count < 0 || first + count > c.cap)
+        return fail(SEIR_ERR_INVALID, "trace range [%d,%d) outside capacity %d", first, first + count, c.cap);
+    if (events && !s->record_events) return fail(SEIR_ERR_STATE, "sampler was created with record_events=0");
+    hipStream_t st = s->ctx->stream;
+    const size_t B = c.B;
+    if (theta)
+        HIP_TRY(hipMemcpyAsync(theta, s->ch.tr_theta + (size_t)first * B * d.P, sizeof(double) * count * B * d.P,
+                               hipMemcpyDeviceToHost, st));
+    if (events)
+        HIP_TRY(hipMemcpyAsync(events, s->ch.tr_events + (size_t)first * B * d.M * d.T * 3,
+                               sizeof(int32_t) * count * B * d.M * d.T * 3, hipMemcpyDeviceToHost, st));
+    if (hmc)
+        HIP_TRY(hipMemcpyAsync(hmc, s->ch.tr_hmc + (size_t)first * B * 3, sizeof(double) * count * B * 3,
+                               hipMemcpyDeviceToHost, st));
+    if (moves)
+        HIP_TRY(hipMemcpyAsync(moves, s->ch.tr_mv + (size_t)first * B * 4 * NMVTR,
+                               sizeof(double) * count * B * 4 * NMVTR, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }

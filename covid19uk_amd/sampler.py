@@ -1,0 +1,156 @@
+"""`ChainSampler`: host handle on the device-resident Metropolis-within-Gibbs
+sampler of libseirhip (C-ABI section "Device-resident Metropolis-within-Gibbs
+sampler" of include/seir_hip.h).
+
+It plays the role of the `GibbsKernel` + `tfp.mcmc.sample_chain` pair the
+reference builds per window (covid19uk/inference/inference.py:60-242): the host
+chooses the window mode (fixed / dual-averaging / dual-averaging + diagonal
+mass adaptation), asks for `n` sweeps, and reads draws and kernel-result
+traces back.  All sampling arithmetic runs in HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+
+import numpy as np
+
+from . import _lib
+from .seir import SeirModel, _dptr
+
+MOVE_KEYS = ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I")   # inference.py:277-280
+
+
+@dataclasses.dataclass
+class Trace:
+    """Draws and kernel results of `count` sweeps for B chains (leading axes [count, B])."""
+    theta: np.ndarray        # [n,B,P] constrained parameter draws
+    events: np.ndarray       # [n,B,M,T,3] int32 (or None)
+    hmc: dict                # is_accepted, target_log_prob, step_size  -> [n,B]
+    moves: dict              # MOVE_KEYS -> dict(is_accepted [n,B], target_log_prob [n,B], proposed_delta [n,B,4,m])
+
+
+class ChainSampler:
+    def __init__(self, model: SeirModel, config: dict, num_chains: int, seed: int = 0,
+                 t_range=None, num_leapfrog_steps: int = 16, trace_capacity: int = 100,
+                 first_chain_id: int = 0, record_events: bool = True):
+        """`config` is the reference's config["Mcmc"] dict: dmax, nmax, m,
+        occult_nmax, num_event_time_updates (mcmc_kernel_factory.py:79-81,106,123)."""
+        self._lib = _lib.load()
+        self.model = model
+        self.B = int(num_chains)
+        self.P, self.M, self.T = model.P, model.M, model.T
+        self.mmax = int(config["m"])
+        if t_range is None:                       # inference.py:336-339
+            t_range = (max(self.T - 21, 0), self.T)
+        self.cap = int(trace_capacity)
+        self.record_events = bool(record_events)
+        desc = _lib.SeirSamplerDesc(
+            num_chains=self.B, dmax=int(config["dmax"]), nmax=int(config["nmax"]), m=self.mmax,
+            occult_nmax=int(config["occult_nmax"]),
+            num_event_time_updates=int(config["num_event_time_updates"]),
+            t_range_lo=int(t_range[0]), t_range_hi=int(t_range[1]),
+            num_leapfrog_steps=int(num_leapfrog_steps), trace_capacity=self.cap,
+            first_chain_id=int(first_chain_id), record_events=int(self.record_events),
+            seed=int(seed) & (2 ** 64 - 1))
+        self._s = ctypes.c_void_p()
+        _lib.check(self._lib.seir_sampler_create(model._ctx, ctypes.byref(desc), ctypes.byref(self._s)))
+
+    def close(self):
+        if getattr(self, "_s", None) is not None and self._s:
+            self._lib.seir_sampler_destroy(self._s)
+            self._s = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state ---------------------------------------------------------------
+    def set_state(self, u, events):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        ev = np.ascontiguousarray(events, dtype=np.float64)
+        if u.shape != (self.B, self.P) or ev.shape != (self.B, self.M, self.T, 3):
+            raise ValueError(f"need u [{self.B},{self.P}] and events [{self.B},{self.M},{self.T},3]")
+        _lib.check(self._lib.seir_sampler_set_state(self._s, _dptr(u), _dptr(ev)))
+
+    def get_state(self):
+        u = np.empty((self.B, self.P))
+        ev = np.empty((self.B, self.M, self.T, 3))
+        lp = np.empty(self.B)
+        _lib.check(self._lib.seir_sampler_get_state(self._s, _dptr(u), _dptr(ev), _dptr(lp)))
+        return u, ev, lp
+
+    def log_prob(self):
+        lp = np.empty(self.B)
+        _lib.check(self._lib.seir_sampler_get_state(self._s, None, None, _dptr(lp)))
+        return lp
+
+    def refresh(self):
+        _lib.check(self._lib.seir_sampler_refresh(self._s))
+
+    # -- kernel parameters -----------------------------------------------------
+    def set_kernel(self, step_size=None, variance=None):
+        ss = None if step_size is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(step_size, dtype=np.float64), (self.B,)))
+        var = None if variance is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(variance, dtype=np.float64), (self.B, self.P)))
+        _lib.check(self._lib.seir_sampler_set_kernel(
+            self._s, None if ss is None else _dptr(ss), None if var is None else _dptr(var)))
+
+    def get_kernel(self):
+        ss, var = np.empty(self.B), np.empty((self.B, self.P))
+        _lib.check(self._lib.seir_sampler_get_kernel(self._s, _dptr(ss), _dptr(var)))
+        return ss, var
+
+    def set_adaptation(self, adapt_step_size=False, adapt_mass=False, num_adaptation_steps=0,
+                       target_accept_prob=0.75, running_variance=None):
+        """running_variance = (count [B], mean [B,P], variance [B,P])."""
+        if adapt_mass:
+            cnt, mean, var = (np.ascontiguousarray(x, dtype=np.float64) for x in running_variance)
+            args = (_dptr(cnt), _dptr(mean), _dptr(var))
+        else:
+            args = (None, None, None)
+        _lib.check(self._lib.seir_sampler_set_adaptation(
+            self._s, int(bool(adapt_step_size)), int(bool(adapt_mass)), int(num_adaptation_steps),
+            float(target_accept_prob), *args))
+
+    # -- sampling ---------------------------------------------------------------
+    def reset_trace(self):
+        _lib.check(self._lib.seir_sampler_reset_trace(self._s))
+
+    def run(self, num_sweeps: int):
+        """Enqueue sweeps (asynchronous)."""
+        _lib.check(self._lib.seir_sampler_run(self._s, int(num_sweeps)))
+
+    def read_trace(self, count: int, first: int = 0, events: bool = True) -> Trace:
+        n = int(count)
+        theta = np.empty((n, self.B, self.P))
+        ev = np.empty((n, self.B, self.M, self.T, 3), dtype=np.int32) if (events and self.record_events) else None
+        hmc = np.empty((n, self.B, 3))
+        mv = np.empty((n, self.B, 4, _lib.MOVE_TRACE))
+        _lib.check(self._lib.seir_sampler_read_trace(
+            self._s, int(first), n, _dptr(theta),
+            None if ev is None else ev.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dptr(hmc), _dptr(mv)))
+        hmc_d = dict(is_accepted=hmc[..., 0] != 0, target_log_prob=hmc[..., 1], step_size=hmc[..., 2])
+        moves = {}
+        for i, key in enumerate(MOVE_KEYS):
+            delta = mv[:, :, i, 2:].reshape(n, self.B, 4, _lib.MMAX)[..., :self.mmax]
+            moves[key] = dict(is_accepted=mv[:, :, i, 0] != 0, target_log_prob=mv[:, :, i, 1],
+                              proposed_delta=delta.astype(np.int64))
+        return Trace(theta=theta, events=ev, hmc=hmc_d, moves=moves)
+
+    def sample(self, num_sweeps: int, events: bool = True) -> Trace:
+        """reset_trace + run + read: the analogue of one `sample_chain` call."""
+        if num_sweeps > self.cap:
+            raise ValueError(f"num_sweeps={num_sweeps} exceeds trace_capacity={self.cap}")
+        self.reset_trace()
+        self.run(num_sweeps)
+        return self.read_trace(num_sweeps, events=events)

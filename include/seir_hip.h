@@ -121,6 +121,80 @@ enum { SEIR_K_SCAN = 0, SEIR_K_GEMM = 1, SEIR_K_SE_VALUE = 2, SEIR_K_SE_GRAD = 3
        SEIR_K_FINISH = 4 };
 int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t iters, float *mean_ms);
 
+
+/* ------------------------------------------------------------------------
+ * Device-resident Metropolis-within-Gibbs sampler.
+ *
+ * Stands in for the kernel stack the reference assembles per window in
+ * inference.py:86-101 / :151-167 / :219-228 and mcmc_kernel_factory.py:14-168:
+ *   GibbsKernel[ (0, HMC [+DualAveraging [+DiagonalMassMatrixAdaptation]]),
+ *                (1, MultiScanKernel(num_event_time_updates,
+ *                      GibbsKernel[ MH(EventTimesUpdate S->E), MH(EventTimesUpdate E->I),
+ *                                   MH(OccultUpdate S->E),     MH(OccultUpdate E->I) ])) ]
+ * and for tfp.mcmc.sample_chain(num_results, ..., trace_fn=trace_results_fn)
+ * (inference.py:107-115,232-240,245-282).  One "sweep" = one posterior draw of
+ * every chain.  All state stays in HBM between calls; draws and traces are
+ * written to a device-side burst buffer and read back with
+ * seir_sampler_read_trace (the reference's per-burst posterior.write_samples,
+ * inference.py:453-468).
+ * ------------------------------------------------------------------------ */
+#define SEIR_MMAX 4           /* upper bound on config["m"] */
+#define SEIR_MOVE_TRACE (2 + 4 * SEIR_MMAX)   /* is_accepted, target_log_prob, m[], t[], delta_t[], x_star[] */
+
+typedef struct {
+    int32_t num_chains;             /* B <= ctx max_chains */
+    int32_t dmax, nmax, m;          /* config["dmax"], ["nmax"], ["m"]   (mcmc_kernel_factory.py:79-81) */
+    int32_t occult_nmax;            /* config["occult_nmax"]             (:106) */
+    int32_t num_event_time_updates; /* config["num_event_time_updates"]  (:123) */
+    int32_t t_range_lo, t_range_hi; /* occult window [lo, hi)            (inference.py:336-339) */
+    int32_t num_leapfrog_steps;     /* 16                                (inference.py:326) */
+    int32_t trace_capacity;         /* sweeps the burst buffer holds */
+    int32_t first_chain_id;         /* global id of chain 0: selects the RNG stream (multi-GPU sharding) */
+    int32_t record_events;          /* 1: record samples/seir for every draw */
+    uint64_t seed;
+} seir_sampler_desc;
+
+int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *desc, seir_sampler **out);
+void seir_sampler_destroy(seir_sampler *s);
+
+/* current_state = [unconstrained params u[B][P], events[B][M][T][3]] (inference.py:563-576); host pointers */
+int seir_sampler_set_state(seir_sampler *s, const double *u, const double *events);
+int seir_sampler_get_state(seir_sampler *s, double *u, double *events, double *logp /* [B] running target_log_prob */);
+
+/* HMC step size per chain and diagonal of the momentum precision ("variance",
+ * i.e. M = diag(1/variance); NULL = identity = momentum_distribution None)
+ * (hmc_kernel_kwargs, inference.py:324-329,384,405-406) */
+int seir_sampler_set_kernel(seir_sampler *s, const double *step_size /* [B] */, const double *variance /* [B][P] */);
+int seir_sampler_get_kernel(seir_sampler *s, double *step_size, double *variance);
+
+/* Window mode (inference.py:60-121 fast, :125-196 slow, :199-242 fixed):
+ * adapt_step_size -> DualAveragingStepSizeAdaptation(target_accept_prob,
+ * num_adaptation_steps) restarted at the current step size;
+ * adapt_mass -> DiagonalMassMatrixAdaptation seeded with the running
+ * variance (count[B], mean[B][P], variance[B][P]) of get_weighted_running_variance
+ * (inference.py:36-47).  Pointers may be NULL when adapt_mass == 0. */
+int seir_sampler_set_adaptation(seir_sampler *s, int32_t adapt_step_size, int32_t adapt_mass,
+                                int32_t num_adaptation_steps, double target_accept_prob,
+                                const double *rv_count, const double *rv_mean, const double *rv_variance);
+
+/* Recompute every cache (state planes, F, tables, running log-prob) from the
+ * event planes and u; called implicitly by set_state. */
+int seir_sampler_refresh(seir_sampler *s);
+
+/* Start a new burst: trace slot 0 = the next sweep. */
+int seir_sampler_reset_trace(seir_sampler *s);
+/* Enqueue num_sweeps sweeps on the context stream (asynchronous). */
+int seir_sampler_run(seir_sampler *s, int32_t num_sweeps);
+/* Blocking read of trace slots [first, first+count):
+ *   theta  [count][B][P]           constrained draws (param_bijector.inverse, inference.py:375)
+ *   events [count][B][M][T][3]     int32 counts (NULL to skip)
+ *   hmc    [count][B][3]           is_accepted, target_log_prob, step_size (inference.py:255-261)
+ *   moves  [count][B][4][SEIR_MOVE_TRACE]  per sub-kernel S->E move, E->I move, S->E occult,
+ *          E->I occult of the LAST inner scan (MultiScanKernel returns the last results,
+ *          inference.py:262-280) */
+int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, double *theta, int32_t *events,
+                            double *hmc, double *moves);
+
 #ifdef __cplusplus
 }
 #endif

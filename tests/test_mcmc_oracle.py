@@ -1,0 +1,160 @@
+"""CPU-only checks of the sampler oracle: the Philox stream against the
+published known-answer vectors, proposal reversibility against independently
+written proposal densities, and basic invariants of a sweep."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import mcmc_oracle as mo
+from oracle import seir_oracle as so
+from tests import helpers as H
+
+CFG = dict(dmax=6, nmax=5, m=2, occult_nmax=4, num_event_time_updates=2)
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors: philox4x32-10
+    r = mo.philox4x32_10(np.array([0], dtype=np.uint64), 0, 0, 0, 0, 0)
+    assert [int(x[0]) for x in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = mo.philox4x32_10(np.array([0xffffffff], dtype=np.uint64), 0xffffffff, 0xffffffff, 0xffffffff,
+                         0xffffffff, 0xffffffff)
+    assert [int(x[0]) for x in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = mo.philox4x32_10(np.array([0x243f6a88], dtype=np.uint64), 0x85a308d3, 0x13198a2e, 0x03707344,
+                         0xa4093822, 0x299f31d0)
+    assert [int(x[0]) for x in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_uniforms_are_open_interval_and_reproducible():
+    a, b = mo.rng_uniform2(123, 4, 5, 6, np.arange(1000))
+    assert a.min() > 0 and a.max() < 1 and b.min() > 0 and b.max() < 1
+    a2, _ = mo.rng_uniform2(123, 4, 5, 6, np.arange(1000))
+    assert np.array_equal(a, a2)
+    assert abs(a.mean() - 0.5) < 0.05
+
+
+# ---- independent proposal densities (written from DESIGN.md, not from mcmc_oracle) ----
+def _closed(k, ev):
+    return so.compute_state(k.initial_state, ev, closed=True)
+
+
+def logq_time_move(k, cfg, ev, tgt, m, t, delta, x):
+    """log q(t, x | m, delta) of moving x `tgt` events of row m from t to t+delta."""
+    K = ev[..., tgt]
+    st = _closed(k, ev)
+    D = int((K[m] > 0).sum())
+    if K[m, t] <= 0:
+        return -math.inf
+    t2 = t + delta
+    lo, hi = min(t, t2), max(t, t2)
+    dec = tgt + 1 if delta > 0 else tgt          # compartment that loses x on (lo, hi]
+    bound = math.inf if dec == 0 else st[m, lo + 1:hi + 1, dec].min()
+    xmax = int(max(0, min(cfg["nmax"], K[m, t], bound)))
+    if x > xmax:
+        return -math.inf
+    return -math.log(D) - math.log(xmax + 1)
+
+
+def logq_occult(k, cfg, ev, tgt, t_range, m, t, x, is_del):
+    K = ev[..., tgt]
+    st = _closed(k, ev)
+    lo, hi = t_range
+    T = k.T
+    rows = K[:, lo:hi].sum(1) > 0
+    Hd = int(rows.sum())
+    if is_del:
+        if Hd == 0 or not rows[m] or K[m, t] <= 0:
+            return -math.inf
+        Dm = int((K[m, lo:hi] > 0).sum())
+        bound = st[m, t + 1:T + 1, tgt + 1].min()
+        xmax = int(max(0, min(cfg["occult_nmax"], K[m, t], bound)))
+        if x > xmax:
+            return -math.inf
+        return math.log(0.5) - math.log(Hd) - math.log(Dm) - math.log(xmax + 1)
+    bound = math.inf if tgt == 0 else st[m, t + 1:T + 1, tgt].min()
+    xmax = int(max(0, min(cfg["occult_nmax"], bound)))
+    if x > xmax:
+        return -math.inf
+    return (math.log(0.5) if Hd > 0 else 0.0) - math.log(k.M) - math.log(hi - lo) - math.log(xmax + 1)
+
+
+@pytest.fixture(scope="module")
+def chain():
+    c = H.build_case("micro_5x24", 3)
+    ch = mo.OracleChain(c["k"], CFG, c["u"], c["events"], seed=11, chain_id=0, t_range=(14, 24))
+    return c, ch
+
+
+def test_event_time_move_log_q_ratio_is_reverse_minus_forward(chain):
+    c, ch = chain
+    k = c["k"]
+    n_checked = 0
+    for sweep in range(60):
+        ch.sweep = sweep
+        for tgt in (0, 1):
+            before = ch.events.copy()
+            out = ch.event_time_move(tgt, 0, tgt)
+            if not out["valid"]:
+                continue
+            new = out["proposed_events"]
+            want = 0.0
+            pd = out["proposed_delta"]
+            for j in range(pd.shape[1]):
+                m, t, delta, x = (int(v) for v in pd[:, j])
+                if delta == 0:
+                    continue
+                want += logq_time_move(k, CFG, new, tgt, m, t + delta, -delta, x) \
+                    - logq_time_move(k, CFG, before, tgt, m, t, delta, x)
+            assert abs(out["log_q_ratio"] - want) < 1e-12, (sweep, tgt, out["log_q_ratio"], want)
+            n_checked += 1
+    assert n_checked > 40
+
+
+def test_occult_log_q_ratio_is_reverse_minus_forward(chain):
+    c, ch = chain
+    k = c["k"]
+    seen = set()
+    for sweep in range(100, 220):
+        ch.sweep = sweep
+        for tgt in (0, 1):
+            before = ch.events.copy()
+            out = ch.occult_move(tgt, 0, 2 + tgt)
+            m, t, sign, x = (int(v) for v in out["proposed_delta"][:, 0])
+            new = out["proposed_events"]
+            is_del = sign < 0
+            fwd = logq_occult(k, CFG, before, tgt, ch.t_range, m, t, x, is_del)
+            rev = logq_occult(k, CFG, new, tgt, ch.t_range, m, t, x, not is_del)
+            assert math.isfinite(fwd)
+            if math.isinf(rev):
+                assert out["log_q_ratio"] == -math.inf
+            else:
+                assert abs(out["log_q_ratio"] - (rev - fwd)) < 1e-12
+            seen.add((tgt, is_del))
+    assert seen == {(0, False), (0, True), (1, False), (1, True)}
+
+
+def test_sweep_keeps_state_feasible_and_log_prob_consistent(chain):
+    c, ch = chain
+    k = c["k"]
+    ch.eps = 0.003
+    for _ in range(15):
+        out = ch.sweep_once()
+        st = so.compute_state(k.initial_state, ch.events, closed=True)
+        assert st.min() >= 0
+        assert ch.events.min() >= 0
+        # I->R events are observed data: never touched (mcmc_kernel_factory.py:129-161)
+        assert np.array_equal(ch.events[..., 2], c["events"][..., 2])
+        assert abs(ch.logp - so.joint_log_prob(ch.u, ch.events, k, "stable")) <= 1e-9 * abs(ch.logp)
+        assert set(out) >= {"hmc", "move/S->E", "move/E->I", "occult/S->E", "occult/E->I", "theta", "events"}
+
+
+def test_dual_averaging_moves_step_size_toward_target():
+    c = H.build_case("micro_3x10", 5)
+    ch = mo.OracleChain(c["k"], dict(CFG, num_event_time_updates=0), c["u"], c["events"], seed=3)
+    ch.eps = 0.5                                    # far too large: rejects
+    ch.set_adaptation(adapt_step=True, num_adaptation_steps=40)
+    acc = []
+    for _ in range(40):
+        acc.append(ch.sweep_once()["hmc"]["is_accepted"])
+    assert ch.eps < 0.5
+    assert np.mean(acc[20:]) > 0.3

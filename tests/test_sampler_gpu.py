@@ -1,0 +1,192 @@
+"""GPU parity of the device-resident sampler (through the C-ABI) against the
+CPU oracle sampler on the same Philox stream: proposals, accept decisions and
+integer traces must agree exactly, continuous quantities to the stated fp64
+tolerances (log-prob rtol 1e-9; parameters rtol 1e-6 after error growth along
+16 leapfrogs x several sweeps)."""
+import numpy as np
+import pytest
+
+from covid19uk_amd import synth
+from oracle import mcmc_oracle as mo
+from oracle import seir_oracle as so
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CFG_SMALL = dict(dmax=8, nmax=6, m=2, occult_nmax=5, num_event_time_updates=3)
+CFG_REF = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5)   # example_config.yaml:26-30
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available()
+    import __graft_entry__ as entry
+    entry.build()
+    from covid19uk_amd.seir import SeirModel
+    from covid19uk_amd.sampler import ChainSampler
+    return SeirModel, ChainSampler
+
+
+def _start(case, B, seed):
+    u = synth.jitter_params(case["u"], B, scale=0.05, seed=seed, T=case["k"].T)
+    ev = np.stack([case["events"]] * B)
+    return u, ev
+
+
+def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6):
+    keys = ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I")
+    for i in range(n):
+        for b in range(B):
+            o = oracles[b][i]
+            assert bool(trace.hmc["is_accepted"][i, b]) == o["hmc"]["is_accepted"], (i, b, "hmc accept")
+            assert abs(trace.hmc["step_size"][i, b] - o["hmc"]["step_size"]) <= 1e-9 * o["hmc"]["step_size"]
+            lp = o["hmc"]["target_log_prob"]
+            assert abs(trace.hmc["target_log_prob"][i, b] - lp) <= 1e-9 * abs(lp), (i, b)
+            for key in keys:
+                got, want = trace.moves[key], o[key]
+                assert np.array_equal(got["proposed_delta"][i, b], want["proposed_delta"]), (i, b, key)
+                assert bool(got["is_accepted"][i, b]) == want["is_accepted"], (i, b, key)
+                lp = want["target_log_prob"]
+                assert abs(got["target_log_prob"][i, b] - lp) <= 1e-9 * abs(lp), (i, b, key)
+            assert np.array_equal(trace.events[i, b], o["events"].astype(np.int32)), (i, b, "events")
+            scale = np.maximum(np.abs(o["theta"]), 1e-3)
+            assert np.max(np.abs(trace.theta[i, b] - o["theta"]) / scale) < theta_rtol, (i, b, "theta")
+
+
+@pytest.mark.parametrize("name,cfg,seed,eps,n", [
+    ("micro_5x24", CFG_SMALL, 1, 0.004, 12),
+    ("ni11", CFG_REF, 2, 0.003, 8),
+    ("micro_17x70", CFG_SMALL, 3, 0.002, 6),
+])
+def test_fixed_kernel_sweeps_match_oracle(api, name, cfg, seed, eps, n):
+    SeirModel, ChainSampler = api
+    case = H.build_case(name, seed, alpha_t_sd=0.005)
+    B = 2
+    u, ev = _start(case, B, seed)
+    oracles = []
+    for b in range(B):
+        ch = mo.OracleChain(case["k"], cfg, u[b], ev[b], seed=77, chain_id=5 + b)
+        ch.eps = eps
+        oracles.append([ch.sweep_once() for _ in range(n)])
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, cfg, B, seed=77, first_chain_id=5, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            lp0 = s.log_prob()
+            for b in range(B):
+                want = so.joint_log_prob(u[b], ev[b], case["k"], "stable")
+                assert abs(lp0[b] - want) <= 1e-9 * abs(want)
+            s.set_kernel(step_size=eps)
+            tr = s.sample(n)
+            _compare(tr, oracles, n, B, cfg)
+            # some of everything must actually have happened
+            assert tr.hmc["is_accepted"].any()
+            assert any(tr.moves[k]["is_accepted"].any() for k in tr.moves)
+
+
+def test_adaptation_windows_match_oracle(api):
+    """Dual averaging, then dual averaging + diagonal mass adaptation (the fast and slow
+    windows of inference.py:60-196), compared step by step."""
+    SeirModel, ChainSampler = api
+    case = H.build_case("micro_5x24", 4, alpha_t_sd=0.005)
+    cfg, B, n = CFG_SMALL, 2, 10
+    u, ev = _start(case, B, 4)
+    P = case["k"].P
+    rv = (np.full(B, 5.0), np.tile(u.mean(0), (B, 1)), np.full((B, P), 0.5))
+    oracles = []
+    for b in range(B):
+        ch = mo.OracleChain(case["k"], cfg, u[b], ev[b], seed=5, chain_id=b)
+        ch.eps = 0.01
+        ch.set_adaptation(adapt_step=True, num_adaptation_steps=n)
+        outs = [ch.sweep_once() for _ in range(n)]
+        ch.set_adaptation(adapt_step=True, adapt_mass=True, num_adaptation_steps=n,
+                          running_variance=(rv[0][b], rv[1][b], rv[2][b]))
+        outs += [ch.sweep_once() for _ in range(n)]
+        oracles.append((outs, ch))
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, cfg, B, seed=5, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.01)
+            s.set_adaptation(adapt_step_size=True, num_adaptation_steps=n)
+            tr1 = s.sample(n)
+            s.set_adaptation(adapt_step_size=True, adapt_mass=True, num_adaptation_steps=n, running_variance=rv)
+            tr2 = s.sample(n)
+            eps, var = s.get_kernel()
+    _compare(tr1, [o[0][:n] for o in oracles], n, B, cfg, theta_rtol=1e-5)
+    _compare(tr2, [o[0][n:] for o in oracles], n, B, cfg, theta_rtol=1e-5)
+    for b in range(B):
+        ch = oracles[b][1]
+        assert abs(eps[b] - ch.eps) <= 1e-8 * ch.eps
+        assert np.max(np.abs(var[b] - ch.var) / ch.var) < 1e-6
+
+
+def test_running_log_prob_matches_full_reevaluation_uk380(api):
+    """Incremental bookkeeping at the BASELINE size: after sweeps with the reference's
+    move configuration the running log-prob equals a from-scratch evaluation of the
+    exported state (C oracle), the cached F equals a fresh contraction (refresh is a
+    no-op within rounding), and the state stays a valid epidemic."""
+    SeirModel, ChainSampler = api
+    case = H.build_case("uk380", 6)
+    B, n = 4, 6
+    u, ev = _start(case, B, 6)
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, CFG_REF, B, seed=9, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.0015)
+            tr = s.sample(n)
+            u1, ev1, lp_run = s.get_state()
+            s.refresh()
+            lp_fresh = s.log_prob()
+    accepted = sum(int(tr.moves[k]["is_accepted"].sum()) for k in tr.moves)
+    assert accepted > 0 and tr.hmc["is_accepted"].any()
+    assert not np.array_equal(ev1, ev), "no event move was applied"
+    for b in range(B):
+        want = H.c_oracle_eval(case["k"], u1[b], ev1[b], stable=1)
+        assert abs(lp_run[b] - want) <= 1e-9 * abs(want), (b, lp_run[b], want)
+        assert abs(lp_fresh[b] - want) <= 1e-9 * abs(want)
+        st = so.compute_state(case["init"], ev1[b], closed=True)
+        assert st.min() >= 0
+        assert np.array_equal(ev1[b][..., 2], ev[b][..., 2])
+        assert np.array_equal(tr.events[-1, b], ev1[b].astype(np.int32))
+        assert abs(tr.moves["occult/E->I"]["target_log_prob"][-1, b] - lp_run[b]) <= 1e-12 * abs(want)
+
+
+def test_chains_are_independent_of_batch_composition(api):
+    """Chain c's draws depend only on (seed, global chain id): running chains {0,1,2,3}
+    together or chain 2 alone (first_chain_id=2) gives bit-identical traces -- the
+    property the multi-GPU sharding relies on."""
+    SeirModel, ChainSampler = api
+    case = H.build_case("ni11", 7)
+    u, ev = _start(case, 4, 7)
+    n = 5
+    with SeirModel(case["cov"], case["init"], max_chains=4) as model:
+        with ChainSampler(model, CFG_REF, 4, seed=3, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.003)
+            tr_all = s.sample(n)
+    with SeirModel(case["cov"], case["init"], max_chains=1) as model:
+        with ChainSampler(model, CFG_REF, 1, seed=3, first_chain_id=2, trace_capacity=n) as s:
+            s.set_state(u[2:3], ev[2:3])
+            s.set_kernel(step_size=0.003)
+            tr_one = s.sample(n)
+    assert np.array_equal(tr_all.theta[:, 2], tr_one.theta[:, 0])
+    assert np.array_equal(tr_all.events[:, 2], tr_one.events[:, 0])
+    assert np.array_equal(tr_all.hmc["target_log_prob"][:, 2], tr_one.hmc["target_log_prob"][:, 0])
+
+
+def test_sampler_argument_errors(api):
+    from covid19uk_amd import _lib
+    SeirModel, ChainSampler = api
+    case = H.build_case("micro_5x24", 8)
+    with SeirModel(case["cov"], case["init"], max_chains=1) as model:
+        with pytest.raises(_lib.SeirError):
+            ChainSampler(model, dict(CFG_SMALL, m=9), 1)
+        with pytest.raises(_lib.SeirError):
+            ChainSampler(model, CFG_SMALL, 2)                 # more chains than the context allows
+        with ChainSampler(model, CFG_SMALL, 1) as s:
+            with pytest.raises(_lib.SeirError):
+                s.run(1)                                      # no state yet
+            bad = case["events"][None].copy()
+            bad[0, 0, 0, 0] = 0.5
+            with pytest.raises(_lib.SeirError):
+                s.set_state(case["u"][None], bad)
