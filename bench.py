@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: posterior samples/sec of the spatial SEIR Metropolis-within-Gibbs
+sampler on the 380-LAD x 365-day UK workload (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one sweep = one posterior draw of every chain on this GPU: an HMC
+update of the P=750 parameters (16 leapfrogs = 17 gradient evaluations) plus
+num_event_time_updates x [S->E move, E->I move, S->E occult, E->I occult]
+Metropolis-Hastings updates of the event tensor (example_config.yaml:26-30), with
+every draw (parameters, event tensor [M,T,3], kernel results) recorded to the
+device-side burst buffer as the reference's sample_chain does
+(covid19uk/inference/inference.py:232-240,453-468).  Chains shard over GPUs with
+no data-path collective (weak scaling: --chains-per-gpu chains on every GPU).
+
+The timed region starts with the chain state resident in HBM; the burst
+buffer's device->host copy and HDF5 write happen between bursts and are
+reported separately (`pcie_inclusive_samples_per_sec`), never as `value`.
+
+Rank 0 prints ONE JSON line (see README "Benchmark").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MCMC_CONFIG = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5)  # example_config.yaml:26-30
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, chip-level parameters
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="uk380", choices=["uk380", "ni11"])
+    ap.add_argument("--chains-per-gpu", type=int, default=8)
+    ap.add_argument("--adapt-sweeps", type=int, default=60, help="untimed dual-averaging sweeps during setup")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-sweeps", type=int, default=0, help="0 = size for ~15 s")
+    ap.add_argument("--seed", type=int, default=20210101)
+    return ap.parse_args()
+
+
+def cpu_baseline(cov, init, events, u0, n_sweeps, seed):
+    """The oracle sampler (full re-evaluation of the joint log-prob for every proposal, as
+    the reference does) on the host cores, C restatement of the density with OpenMP."""
+    from oracle import c_binding, mcmc_oracle as mo, seir_oracle as so
+    k = so.make_constants(cov.C, cov.N, cov.W, cov.weekday, cov.area, cov.adjacency, init)
+    cores = len(os.sched_getaffinity(0))
+    c_binding.set_threads(cores)
+    lp = lambda u, ev: c_binding.evaluate(k, u, ev, 1)                      # noqa: E731
+    lpg = lambda u, ev: c_binding.evaluate(k, u, ev, 1, want_grad=True)     # noqa: E731
+    ch = mo.OracleChain(k, MCMC_CONFIG, u0, events, seed=seed, chain_id=0, log_prob_fn=lp, log_prob_grad_fn=lpg)
+    ch.eps = 2e-5
+    t0 = time.perf_counter()
+    ch.sweep_once()
+    one = time.perf_counter() - t0
+    n = n_sweeps if n_sweeps > 0 else max(2, min(40, int(15.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ch.sweep_once()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "posterior samples/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} sweeps of 1 chain, oracle/mcmc_oracle.py + oracle/seir_oracle.c (OpenMP, "
+                      f"{cores} threads), {ch.n_evals} full log-prob evaluations, same workload"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and not (world == 1 and a.gpus == 1):
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.barrier()
+    from covid19uk_amd import synth
+    from covid19uk_amd.sampler import ChainSampler
+    from covid19uk_amd.seir import SeirModel
+
+    B = a.chains_per_gpu
+    cov = synth.make_covariates(a.workload, a.seed)
+    events, init, truth = synth.simulate_epidemic(cov, a.seed)
+    u_true = synth.unconstrain(synth.pack_params(truth, cov.M, cov.T))
+    # every chain of the job gets its own start point (global chain id = rank*B + b)
+    u_all = synth.jitter_params(u_true, world * B, scale=0.002, seed=7, T=cov.T)
+    u0 = u_all[rank * B:(rank + 1) * B].copy()
+    ev0 = np.stack([events] * B)
+    K, W = a.steps, a.warmup
+
+    model = SeirModel(cov, init, max_chains=B, device=local)
+    sampler = ChainSampler(model, MCMC_CONFIG, B, seed=a.seed, first_chain_id=rank * B,
+                           trace_capacity=max(K, 1), record_events=True)
+    sampler.set_state(u0, ev0)
+    sampler.set_kernel(step_size=2e-5)
+    # setup (untimed): a short dual-averaging window, then pool the step size over ALL chains
+    # of the job (the optional cross-chain gather of BASELINE.json config 4: RCCL all_gather).
+    if a.adapt_sweeps > 0:
+        sampler.set_adaptation(adapt_step_size=True, num_adaptation_steps=a.adapt_sweeps)
+        sampler.reset_trace()
+        sampler.run(a.adapt_sweeps)
+        model.sync()
+    eps, _ = sampler.get_kernel()
+    log_eps = torch.tensor(np.log(eps), device=f"cuda:{local}")
+    if world > 1:
+        gathered = [torch.empty_like(log_eps) for _ in range(world)]
+        dist.all_gather(gathered, log_eps)
+        log_eps = torch.cat(gathered)
+    pooled = float(torch.exp(log_eps.mean()).cpu())
+    sampler.set_adaptation(adapt_step_size=False)
+    sampler.set_kernel(step_size=pooled)
+
+    # warm-up steps, then the timed region
+    sampler.reset_trace()
+    sampler.run(W)
+    model.sync()
+    sampler.reset_trace()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    model.sync()
+    t0 = time.perf_counter()
+    model.timer_start()
+    sampler.run(K)
+    ev_ms = model.timer_stop()              # blocks until the K sweeps are done (HIP events, ctx stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    elapsed = float(t_all.cpu())
+
+    # draws leave the device between bursts: D2H of the whole burst buffer (PCIe-inclusive rate)
+    t1 = time.perf_counter()
+    tr = sampler.read_trace(min(K, sampler.cap))
+    d2h = time.perf_counter() - t1
+    acc = {"hmc": float(tr.hmc["is_accepted"].mean())}
+    for key, mv in tr.moves.items():
+        acc[key] = float(mv["is_accepted"].mean())
+    finite = bool(np.isfinite(tr.hmc["target_log_prob"]).all())
+
+    # dominant kernel of the sweep: the gradient kernel (17 launches per sweep)
+    grad_ms = sampler.time_grad_kernel(200)
+    M, T, P = cov.M, cov.T, model.P
+    alg_bytes = B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
+    achieved = alg_bytes / (grad_ms * 1e-3) / 1e9
+
+    # secondary metric: full log_prob evaluations/sec through the stateless C-ABI
+    dev = torch.device("cuda", local)
+    ut = torch.tensor(u0, device=dev)
+    evt = torch.tensor(ev0, device=dev)
+    lp = torch.empty(B, dtype=torch.float64, device=dev)
+    gr = torch.empty(B, P, dtype=torch.float64, device=dev)
+    evals = {}
+    for name, g in (("value", None), ("value_and_grad", gr)):
+        for _ in range(3):
+            model.log_prob_dev(ut, evt, lp, g)
+        model.sync()
+        model.timer_start()
+        for _ in range(50):
+            model.log_prob_dev(ut, evt, lp, g)
+        evals[name] = B * 50 / (model.timer_stop() * 1e-3)
+
+    if rank == 0:
+        out = {
+            "metric": "posterior samples/sec, 380-LAD UK SEIR" if a.workload == "uk380"
+                      else "posterior samples/sec, 11-LAD NI SEIR",
+            "value": world * B * K / elapsed,
+            "unit": "posterior samples/sec",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: M={M} LADs x T={T} days, P={P} parameters",
+                       "chains_per_gpu": B, "chains_total": world * B,
+                       "sweep": "HMC(16 leapfrogs) + 5 x [S->E move, E->I move, S->E occult, E->I occult]",
+                       "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] + kernel results per sweep",
+                       "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"kernel": "k_se<GRAD=true,SRC=planes> (S->E term + gradient sums, all chains)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": 1e3 * grad_ms,
+                         "launches_per_sweep": 17},
+            "log_prob_evals_per_sec": evals,
+            "hip_event_ms_per_step": ev_ms / K,
+            "pcie_inclusive_samples_per_sec": world * B * K / (elapsed + d2h),
+            "acceptance": acc, "step_size": pooled, "all_log_probs_finite": finite,
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed)
+        print(json.dumps(out), flush=True)
+    sampler.close()
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,8 @@ _SIGNATURES = {
     "seir_sampler_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "seir_sampler_read_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_double_p,
                                                ctypes.POINTER(ctypes.c_int32), c_double_p, c_double_p]),
+    "seir_sampler_time_grad_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32,
+                                                     ctypes.POINTER(ctypes.c_float)]),
 }
 
 _lib = None

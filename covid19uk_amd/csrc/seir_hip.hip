@@ -735,3 +735,21 @@ extern "C" int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t c
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
+
+extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
+    if (!mean_ms || iters < 1) return fail(SEIR_ERR_INVALID, "bad iters/mean_ms");
+    seir_ctx *ctx = s->ctx;
+    launch_se<1>(ctx, s->cfg.B, true);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; ++i) launch_se<1>(ctx, s->cfg.B, true);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    HIP_TRY(hipGetLastError());
+    *mean_ms = ms / iters;
+    return 0;
+}

@@ -154,3 +154,9 @@ class ChainSampler:
         self.reset_trace()
         self.run(num_sweeps)
         return self.read_trace(num_sweeps, events=events)
+
+    def time_grad_kernel(self, iters: int = 100) -> float:
+        """Mean duration (ms) of the sweep's gradient kernel, HIP events on the context stream."""
+        ms_ = ctypes.c_float()
+        _lib.check(self._lib.seir_sampler_time_grad_kernel(self._s, int(iters), ctypes.byref(ms_)))
+        return float(ms_.value)

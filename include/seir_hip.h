@@ -195,6 +195,12 @@ int seir_sampler_run(seir_sampler *s, int32_t num_sweeps);
 int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, double *theta, int32_t *events,
                             double *hmc, double *moves);
 
+/* Mean launch duration (ms, HIP events on the context stream) of the sweep's
+ * gradient kernel -- the S->E term + d/d eta sums over all B chains that runs
+ * num_leapfrog_steps+1 times per sweep -- replayed `iters` times on the current
+ * chain state (it only writes its partial-sum buffers). */
+int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms);
+
 #ifdef __cplusplus
 }
 #endif

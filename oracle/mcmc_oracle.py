@@ -76,8 +76,12 @@ class OracleChain:
     """One chain of the sampler with the device's exact draw protocol."""
 
     def __init__(self, k: so.ModelConstants, config: dict, u, events, seed=0, chain_id=0,
-                 t_range=None, num_leapfrog_steps=16):
+                 t_range=None, num_leapfrog_steps=16, log_prob_fn=None, log_prob_grad_fn=None):
+        """log_prob_fn(u, events) / log_prob_grad_fn(u, events) default to the NumPy oracle;
+        the C restatement (oracle/seir_oracle.c) can be passed for large cases."""
         self.k = k
+        self._lp_fn = log_prob_fn or (lambda u_, ev_: so.joint_log_prob(u_, ev_, k, "stable"))
+        self._lpg_fn = log_prob_grad_fn or (lambda u_, ev_: so.joint_log_prob_and_grad(u_, ev_, k))
         self.cfg = dict(config)
         self.u = np.array(u, dtype=np.float64)
         self.events = np.array(events, dtype=np.float64)
@@ -90,7 +94,7 @@ class OracleChain:
         self.n_adapt, self.target = 0, 0.75
         self.da = dict(err=0.0, step=0.0, logavg=0.0, mu=math.log(10 * self.eps))
         self.rv_n, self.rv_mean, self.rv_m2 = 0.0, np.zeros(k.P), np.zeros(k.P)
-        self.logp = so.joint_log_prob(self.u, self.events, k, "stable")
+        self.logp = self._lp_fn(self.u, self.events)
         self.n_evals = 0
 
     # -- configuration ------------------------------------------------------
@@ -111,11 +115,11 @@ class OracleChain:
 
     def _lp(self, u, events):
         self.n_evals += 1
-        return so.joint_log_prob(u, events, self.k, "stable")
+        return self._lp_fn(u, events)
 
     def _lp_grad(self, u):
         self.n_evals += 1
-        return so.joint_log_prob_and_grad(u, self.events, self.k)
+        return self._lpg_fn(u, self.events)
 
     # -- HMC (PreconditionedHamiltonianMonteCarlo, diag mass M = 1/var) -------
     def hmc_step(self):

@@ -25,6 +25,7 @@
  * alpha_0, alpha_t[T-1], spatial_effect[M].
  */
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -206,3 +207,7 @@ double seir_oracle_eval_flat(int M, int T, const double *Cstar, const double *N,
     oracle_consts c = {M, T, Cstar, N, W, weekday_c, log_area_c, car_Q, car_half_logdet, init_state};
     return seir_oracle_eval(&c, u, events, stable, grad);
 }
+
+/* thread count of the OpenMP loops above (cpu_baseline reports it as "cores") */
+void seir_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int seir_oracle_max_threads(void) { return omp_get_max_threads(); }

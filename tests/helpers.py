@@ -1,7 +1,5 @@
 """Shared builders for the parity tests (seeded inputs, oracle handles)."""
-import ctypes
 import os
-import subprocess
 
 import numpy as np
 
@@ -50,38 +48,12 @@ def build_case(name, seed=20210101, alpha_t_sd=0.0):
                 k=oracle_constants(cov, init))
 
 
-_C_ORACLE = None
+from oracle import c_binding
 
 
 def c_oracle():
-    """ctypes handle on oracle/libseir_oracle.so (built on demand with make)."""
-    global _C_ORACLE
-    if _C_ORACLE is None:
-        path = os.path.join(ROOT, "oracle", "libseir_oracle.so")
-        src = os.path.join(ROOT, "oracle", "seir_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-        lib = ctypes.CDLL(path)
-        dp = ctypes.POINTER(ctypes.c_double)
-        lib.seir_oracle_eval_flat.restype = ctypes.c_double
-        lib.seir_oracle_eval_flat.argtypes = [ctypes.c_int, ctypes.c_int] + [dp] * 6 + \
-            [ctypes.c_double, dp, dp, dp, ctypes.c_int, dp]
-        _C_ORACLE = lib
-    return _C_ORACLE
+    return c_binding.lib()
 
 
 def c_oracle_eval(k, u, events, stable=1, want_grad=False):
-    lib = c_oracle()
-    dp = ctypes.POINTER(ctypes.c_double)
-
-    def p(a):
-        a = np.ascontiguousarray(a, dtype=np.float64)
-        return a, a.ctypes.data_as(dp)
-    keep = [p(x) for x in (k.Cstar, k.N, k.W, k.weekday_c, k.log_area_c, k.Q)]
-    init = p(k.initial_state)
-    uu, ev = p(u), p(events)
-    g = np.zeros(k.P)
-    lp = lib.seir_oracle_eval_flat(k.M, k.T, *[x[1] for x in keep], k.half_logdet_Q,
-                                   init[1], uu[1], ev[1], int(stable),
-                                   g.ctypes.data_as(dp) if want_grad else None)
-    return (lp, g) if want_grad else lp
+    return c_binding.evaluate(k, u, events, stable, want_grad)
