@@ -14,6 +14,7 @@ __constant__ double c_lfact[LFACT_TABLE];
 // log Gamma(n+1) for integer-valued n >= 0.  Table below 64, Stirling series
 // above: (x-1/2)ln x - x + ln(2 pi)/2 + 1/(12x) - 1/(360x^3) + 1/(1260x^5) - 1/(1680x^7),
 // whose first dropped term is < 1e-19 at x >= 65.
+__device__ __forceinline__ double lfact(double n, const double2 *tab);
 __device__ __forceinline__ double lfact(double n) {
     if (n < (double)LFACT_TABLE) return c_lfact[(int)n];
     const double x = n + 1.0;
@@ -28,7 +29,89 @@ __device__ __forceinline__ double lbinom(double n, double k) {
     return lfact(n) - lfact(k) - lfact(n - k);
 }
 
-// log(1 - exp(-r)); NaN for r < 0 exactly as log(1 - exp(-r)) in the reference.
+// ---------------------------------------------------------------------------
+// Table-driven log for positive normal x (the ocml log costs ~400 cycles per
+// wave-op on gfx950, a third of the whole cell).  x = 2^k m, m in [1,2);
+// i = top 7 mantissa bits; tab[i] = (invc, logc) with c ~ 1 + (i+1/2)/128,
+// invc = fl(1/c), logc = -log(invc) (long double on the host); f = m invc - 1
+// (one fma, |f| < 2^-7.9); log x = k ln2 + logc + log1p(f), log1p by its
+// degree-8 Taylor polynomial (next term < 2^-75).  Absolute error < 2e-16 +
+// 1 ulp(result): used only where |log x| >= 2 (x <= 1/8), so ~1e-16 relative.
+// The table lives in LDS (filled from Consts.logtab by log_table_to_lds).
+// ---------------------------------------------------------------------------
+constexpr int LOGTAB_N = 128;
+__device__ __forceinline__ double fast_log(double x, const double2 *tab) {
+    const long long bits = __double_as_longlong(x);
+    const int k = (int)((bits >> 52) & 0x7ff) - 1023;
+    const int i = (int)((bits >> 45) & 127);
+    const double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    const double2 tc = tab[i];
+    const double f = fma(m, tc.x, -1.0);
+    double p = fma(f, -0.125, 0.14285714285714285);
+    p = fma(f, p, -0.16666666666666666);
+    p = fma(f, p, 0.2);
+    p = fma(f, p, -0.25);
+    p = fma(f, p, 0.33333333333333331);
+    p = fma(f, p, -0.5);
+    p = fma(f * f, p, f);
+    const double kd = (double)k;
+    return fma(kd, 0.69314718055994529, tc.y) + fma(kd, 2.3190468138462996e-17, p);
+}
+
+// Stirling with the table log (the hot kernels' form of lfact / lbinom)
+__device__ __forceinline__ double lfact(double n, const double2 *tab) {
+    if (n < (double)LFACT_TABLE) return c_lfact[(int)n];
+    const double x = n + 1.0;
+    const double xi = 1.0 / x, xi2 = xi * xi;
+    const double corr = xi * (8.333333333333333e-2 - xi2 * (2.777777777777778e-3 - xi2 * (7.936507936507937e-4 - xi2 * 5.952380952380952e-4)));
+    return (x - 0.5) * fast_log(x, tab) - x + 0.9189385332046727 + corr;
+}
+__device__ __forceinline__ double lbinom(double n, double k, const double2 *tab) {
+    if (k < 0.0 || k > n) return -INFINITY;
+    return lfact(n, tab) - lfact(k, tab) - lfact(n - k, tab);
+}
+
+// reciprocal of a positive normal double: v_rcp_f64 + two Newton steps
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
+__device__ __forceinline__ void log_table_to_lds(double2 *lds_tab, const double2 *__restrict__ gtab) {
+    if (threadIdx.x < LOGTAB_N) lds_tab[threadIdx.x] = gtab[threadIdx.x];
+    __syncthreads();
+}
+
+// L = log(1 - exp(-r)) and inv = 1/expm1(r) for a rate*dt r.  r < 0 gives NaN
+// (the reference's log(1 - exp(-r)) does too).  Daily hazards are small, so the
+// common path is a series around 0 (|rel err| < 3e-16 for r <= 1/8, checked
+// against mpmath in tests/test_abi.py::test_series_constants):
+//   log((1-e^-r)/r) = -r/2 + r^2/24 - r^4/2880 + r^6/181440 - r^8/9676800
+//   1/expm1(r)      = 1/r - 1/2 + r/12 - r^3/720 + r^5/30240 - r^7/1209600
+// with the table log and the Newton reciprocal above instead of expm1 + log + divide.
+constexpr double L1ME_SERIES_MAX = 0.125;
+constexpr double L1ME_SERIES_MIN = 1e-300;
+__device__ __forceinline__ void l1me_inv(double r, double &L, double &inv, const double2 *tab) {
+    if (r >= L1ME_SERIES_MIN && r <= L1ME_SERIES_MAX) {
+        const double r2 = r * r, ri = fast_rcp(r);
+        L = fast_log(r, tab) + r * (-0.5 + r * (4.1666666666666664e-2 - r2 * (3.4722222222222224e-4 - r2 * (5.5114638447971785e-6 - r2 * 1.0333994708994709e-7))));
+        inv = ri - 0.5 + r * (8.3333333333333329e-2 - r2 * (1.3888888888888889e-3 - r2 * (3.3068783068783071e-5 - r2 * 8.2671957671957672e-7)));
+    } else {                       // r > 1/8: 1 - e^-r has no cancellation; r < 0: log of a negative -> NaN
+        const double e = exp(-r), om = 1.0 - e;
+        L = log(om);
+        inv = e / om;
+    }
+}
+__device__ __forceinline__ double log1mexp(double r, const double2 *tab) {
+    if (r >= L1ME_SERIES_MIN && r <= L1ME_SERIES_MAX) {
+        const double r2 = r * r;
+        return fast_log(r, tab) + r * (-0.5 + r * (4.1666666666666664e-2 - r2 * (3.4722222222222224e-4 - r2 * (5.5114638447971785e-6 - r2 * 1.0333994708994709e-7))));
+    }
+    return r > L1ME_SERIES_MAX ? log(1.0 - exp(-r)) : log(-expm1(-r));
+}
+// same without a table (cold paths)
 __device__ __forceinline__ double log1mexp(double r) { return log(-expm1(-r)); }
 
 __device__ __forceinline__ double softplus(double x) {
@@ -57,6 +140,48 @@ __device__ __forceinline__ T wave_incl_scan(T v, int lane) {
         if (lane >= o) v += n;
     }
     return v;
+}
+
+// inclusive suffix sum across the 64 lanes of a wave (lane l gets sum_{j>=l})
+__device__ __forceinline__ double wave_incl_suffix_scan(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double n = __shfl_down(v, o, WAVE);
+        if (lane + o < WAVE) v += n;
+    }
+    return v;
+}
+
+// Exclusive prefix sum over a 256-thread block (thread order); `sh` needs 4
+// elements.  Two barriers.  `total` receives the block sum.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_256(T v, T *sh, T &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T inc = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    T base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < wave) base += sh[k];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    return base + inc - v;
+}
+
+// Inclusive suffix sum over a 256-thread block: thread i gets sum_{j>=i} v_j.
+__device__ __forceinline__ double block_incl_suffix_scan_256(double v, double *sh, double &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double inc = wave_incl_suffix_scan(v, lane);
+    __syncthreads();
+    if (lane == 0) sh[wave] = inc;
+    __syncthreads();
+    double tail = 0.0;
+#pragma unroll
+    for (int k = 3; k >= 0; --k)
+        if (k > wave) tail += sh[k];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    return inc + tail;
 }
 
 // Sum over a 256-thread block; `sh` needs 4 doubles.  Result in every thread.

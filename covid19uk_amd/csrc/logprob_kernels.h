@@ -11,7 +11,8 @@
 //   k_se        both         S->E chain-binomial term (+ d/d eta row/column sums, d/d psi)
 //   k_finish    both         reduction, I->R term, gradient assembly
 //
-// Per-chain workspace (HBM), rows padded to Mp = ceil16(M), days to Tp = ceil64(T), pads zero:
+// Per-chain workspace (HBM), rows padded to Mp = ceil64(M), days to Tp = ceil64(T), pads zero
+// (zero pads contribute exactly 0 to every sum, so the cell kernels carry no bounds masks):
 //   API path     Xn fp64 (I/N), KS int2 (k_se, S-k_se), F fp64
 //   sampler path int32 planes K[3] (events), St[3] (S,E,I at start of day), F fp64
 #pragma once
@@ -20,15 +21,19 @@
 namespace seir {
 
 constexpr int SCAN_ROWS = 8;    // rows per k_scan workgroup (2 per wave)
-constexpr int SE_TM = 16;       // k_se tile: 16 rows x 64 days per workgroup (4 rows per wave)
+constexpr int SE_RW = 8;        // k_se: rows per wave; tile = (4*SE_RW) rows x 64 days per workgroup
+constexpr int SE_TM = 4 * SE_RW;
 constexpr int NSCAL = 16;       // per-chain scalar block
 enum { SC_PSI = 0, SC_SIG, SC_BETA, SC_G0, SC_G1, SC_A0, SC_S0, SC_S1, SC_PRIOR, SC_JAC };
 
 struct Dims {
     int M, T, Mp, Tp, Kp, P, Pp;
+    int b0;                 // first chain handled by this launch (chain groups on separate streams)
     int nrb_scan;           // row blocks of k_scan
-    int nmt, ntc;           // k_se tiles: Mp/16 row tiles, Tp/64 day chunks
+    int nmt, ntc;           // k_se tiles: Mp/SE_TM row tiles, Tp/64 day chunks
     double nu, dt, rate_floor, car_half_logdet;
+    double L_ei;            // log(1 - exp(-nu dt))
+    double prior_const;     // parameter-free part of the summed prior log-densities
 };
 
 struct Consts {
@@ -38,6 +43,10 @@ struct Consts {
     const double *init;            // [Mp][4]
     const int *Qrow, *Qcol;        // CSR of car_Q
     const double *Qval;
+    const double2 *logtab;         // [LOGTAB_N] (1/c, log c) of device_math.h fast_log
+    int qw;                        // ELL width of car_Q (0: use the CSR arrays)
+    const int *Qell_col;           // [qw][Mp]
+    const double *Qell_val;        // [qw][Mp]
 };
 
 struct Work {
@@ -68,12 +77,14 @@ struct Work {
 template <int SRC>
 __global__ __launch_bounds__(256) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
     extern __shared__ double lds[];                 // [4][Tp][2]
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double2 ltab[LOGTAB_N];
+    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *mycol = lds + (size_t)wave * d.Tp * 2;
     for (int i = lane; i < d.Tp * 2; i += WAVE) mycol[i] = 0.0;
+    log_table_to_lds(ltab, c.logtab);
 
     const double r_ei = d.nu * d.dt;
-    const double L_ei = log1mexp(r_ei);
+    const double L_ei = d.L_ei;
     const int nch = d.Tp / WAVE;
     constexpr int RPW = SCAN_ROWS / 4;
     for (int r = 0; r < RPW; ++r) {
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(256) void k_scan(Dims d, Consts c, Work w, const do
                 w.St[2][rowoff + t] = valid ? (int)I : 0;
             }
             if (valid) {
-                rc += lbinom(S, kse) + lbinom(E, kei) + lbinom(I, kir);
+                rc += lbinom(S, kse, ltab) + lbinom(E, kei, ltab) + lbinom(I, kir, ltab);
                 rc += kei * L_ei - (E - kei) * r_ei;
                 mycol[t * 2 + 0] += kir;
                 mycol[t * 2 + 1] += I - kir;
@@ -140,14 +151,18 @@ __global__ __launch_bounds__(256) void k_scan(Dims d, Consts c, Work w, const do
 // the sum of the row constants.
 __global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) {
     __shared__ double sh[4];
-    const int b = blockIdx.x;
+    const int b = d.b0 + blockIdx.x;
     for (int t = threadIdx.x; t < d.Tp; t += 256) {
-        double a = 0.0, e = 0.0;
-        for (int rb = 0; rb < d.nrb_scan; ++rb) {
-            const double *p = w.colIR + (((size_t)b * d.nrb_scan + rb) * d.Tp + t) * 2;
-            a += p[0];
-            e += p[1];
+        double a = 0.0, e = 0.0, a1 = 0.0, e1 = 0.0;
+        const double2 *p = (const double2 *)w.colIR + (size_t)b * d.nrb_scan * d.Tp + t;
+        int rb = 0;
+        for (; rb + 3 < d.nrb_scan; rb += 4) {          // integer-valued sums: any order is exact
+            const double2 v0 = p[(size_t)rb * d.Tp], v1 = p[(size_t)(rb + 1) * d.Tp];
+            const double2 v2 = p[(size_t)(rb + 2) * d.Tp], v3 = p[(size_t)(rb + 3) * d.Tp];
+            a += v0.x + v2.x; e += v0.y + v2.y; a1 += v1.x + v3.x; e1 += v1.y + v3.y;
         }
+        for (; rb < d.nrb_scan; ++rb) { const double2 v = p[(size_t)rb * d.Tp]; a += v.x; e += v.y; }
+        a += a1; e += e1;
         w.Kir[(size_t)b * d.Tp + t] = a;
         w.Dir[(size_t)b * d.Tp + t] = e;
     }
@@ -172,7 +187,7 @@ __host__ __device__ inline int gemm_lda(int Kp) { return ((gemm_kc(Kp) + 31) / 3
 
 __global__ __launch_bounds__(256) void k_gemm(Dims d, Consts c, Work w) {
     extern __shared__ double lds[];                 // [16][lda]
-    const int b = blockIdx.z, m0 = blockIdx.y * 16;
+    const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lda = gemm_lda(d.Kp), kc = gemm_kc(d.Kp);
     const int tt0 = (blockIdx.x * 4 + wave) * GEMM_TT;     // first 16-wide t tile of this wave
@@ -236,16 +251,8 @@ __device__ inline void param_tables(const Dims &d, const Consts &c, const Work &
     double s = 0.0, q_at = 0.0;
     for (int t = t_lo; t < t_hi; ++t)
         if (t >= 1) { const double v = at[t - 1]; s += v; q_at += v * v; }
-    __syncthreads();
-    seg[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {           // Hillis-Steele inclusive scan
-        const double v = tid >= o ? seg[tid - o] : 0.0;
-        __syncthreads();
-        seg[tid] += v;
-        __syncthreads();
-    }
-    double acc = a0 + (tid ? seg[tid - 1] : 0.0);
+    double tot_unused;
+    double acc = a0 + block_excl_scan_256(s, seg, tot_unused);
     for (int t = t_lo; t < t_hi; ++t) {
         if (t >= 1) acc += at[t - 1];
         w.ea[(size_t)b * d.Tp + t] = exp(acc);
@@ -262,15 +269,15 @@ __device__ inline void param_tables(const Dims &d, const Consts &c, const Work &
     quad = block_sum_256(quad, sh);
     q_at = block_sum_256(q_at, sh);
     if (tid == 0) {
-        const double LOG_2PI = 1.8378770664093453;
-        double lp = -0.5 * a0 * a0 / 100.0 - log(10.0) - 0.5 * LOG_2PI;              // alpha_0 ~ N(0,10)
-        lp += -0.5 * beta * beta - 0.5 * LOG_2PI;                                    // beta_area ~ N(0,1)
-        lp += 3.0 * log(10.0) - 0.6931471805599453 + 2.0 * log(psi) - 10.0 * psi;    // psi ~ Gamma(3,10)
-        lp += -0.5 * q_at / (0.005 * 0.005) - (d.T - 1) * (log(0.005) + 0.5 * LOG_2PI);
-        lp += 0.5 * log(2.0 / M_PI) - log(0.1) - sig * sig / 0.02;                   // HalfNormal(0.1)
-        lp += -0.5 * quad + d.car_half_logdet - 0.5 * d.M * LOG_2PI;                 // CAR
-        lp += -0.5 * g0 * g0 / 1.0e4 - log(100.0) - 0.5 * LOG_2PI;
-        lp += -0.5 * g1 * g1 / 1.0e4 - log(100.0) - 0.5 * LOG_2PI;
+        // model_spec.py:140-198; the parameter-free normalisers are folded into d.prior_const
+        double lp = d.prior_const;
+        lp += -0.5 * a0 * a0 / 100.0;                                 // alpha_0 ~ N(0,10)
+        lp += -0.5 * beta * beta;                                     // beta_area ~ N(0,1)
+        lp += 2.0 * log(psi) - 10.0 * psi;                            // psi ~ Gamma(3,10)
+        lp += -0.5 * q_at / (0.005 * 0.005);                          // alpha_t ~ N(0, 0.005)
+        lp += -sig * sig / 0.02;                                      // sigma_space ~ HalfNormal(0.1)
+        lp += -0.5 * quad;                                            // CAR, precision form
+        lp += -0.5 * (g0 * g0 + g1 * g1) / 1.0e4;                     // gamma0, gamma1 ~ N(0,100)
         double *sc = w.scal + (size_t)b * NSCAL;
         sc[SC_PSI] = psi; sc[SC_SIG] = sig; sc[SC_BETA] = beta; sc[SC_G0] = g0; sc[SC_G1] = g1;
         sc[SC_A0] = a0;
@@ -285,81 +292,99 @@ __device__ inline void param_tables(const Dims &d, const Consts &c, const Work &
 __global__ __launch_bounds__(256) void k_params(Dims d, Consts c, Work w, const double *__restrict__ u_all) {
     __shared__ double sh[4];
     __shared__ double seg[256];
-    param_tables(d, c, w, blockIdx.x, u_all + (size_t)blockIdx.x * d.P, seg, sh);
+    param_tables(d, c, w, d.b0 + blockIdx.x, u_all + (size_t)(d.b0 + blockIdx.x) * d.P, seg, sh);
 }
 
 // ---------------------------------------------------------------------------
 // k_se: the S->E chain-binomial term and its eta/psi derivatives.
 //   lambda_mt = exp(eta_mt) (I + psi W_t F_mt)/N_m + 1e-9      model_spec.py:258-266
 //   ll = k log(1-exp(-r)) - (S-k) r,  r = lambda dt   (multiply_no_nan: k==0 drops the log)
-// Tile = 16 rows x 64 days per workgroup; wave = 4 rows, lane = day: every
-// plane is read as 512-B coalesced row segments, 4 independent cells per lane.
+// Tile = SE_TM rows x 64 days per workgroup; wave = SE_RW rows, lane = day: every plane is
+// read as 512-B coalesced row segments.  All of a lane's loads are issued before any
+// arithmetic and the SE_RW cells are independent instruction streams, which is what
+// fills the fp64 pipe (a dependent fp64 op has ~32 cycles latency on gfx950).  Zero pads
+// contribute exactly zero, so there are no bounds masks.
 // ---------------------------------------------------------------------------
+constexpr int SE_RS = 72;       // LDS row stride (doubles) of the row-sum transpose: conflict-free b64 reads
+
 template <bool GRAD, int SRC>
 __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     __shared__ double colbuf[4][WAVE];
-    __shared__ double shl[4], shp[4];
-    const int b = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double llbuf[4][WAVE], psibuf[4][WAVE];
+    __shared__ double rowbuf[GRAD ? 4 * SE_RW * SE_RS : 1];
+    __shared__ double2 ltab[LOGTAB_N];
+    const int b = d.b0 + blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * WAVE + lane;
-    const int m0 = blockIdx.y * SE_TM + wave * 4;
-    const bool valid = t < d.T;
+    const int m0 = blockIdx.y * SE_TM + wave * SE_RW;
+    if (threadIdx.x < LOGTAB_N) ltab[threadIdx.x] = c.logtab[threadIdx.x];   // barrier below, after the loads
     const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
-    const double ea_t = valid ? w.ea[(size_t)b * d.Tp + t] : 0.0;
-    const double Wt = valid ? c.W[t] : 0.0;
+    const double ea_t = w.ea[(size_t)b * d.Tp + t];
+    const double Wt = c.W[t];
     const double psiW = psi * Wt;
-    double ll = 0.0, gpsi = 0.0, colacc = 0.0, rowacc[4];
+    const size_t q0 = ((size_t)b * d.Mp + m0) * d.Tp + t;
+    double F[SE_RW], I[SE_RW], kse[SE_RW], snk[SE_RW], eb[SE_RW];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rowacc[r] = 0.0;
-        const int m = m0 + r;
-        if (m >= d.M) continue;                       // wave-uniform
-        const size_t q = ((size_t)b * d.Mp + m) * d.Tp + t;
-        const double F = w.F[q];
-        double I, kse, snk;
-        int ki;
+    for (int r = 0; r < SE_RW; ++r) {
+        const size_t q = q0 + (size_t)r * d.Tp;
+        F[r] = w.F[q];
+        eb[r] = w.eb[(size_t)b * d.Mp + m0 + r];
         if (SRC == 0) {
             const int2 ks = w.KS[q];
-            I = rint(w.Xn[q] * c.N[m]);
-            ki = ks.x; kse = (double)ks.x; snk = (double)ks.y;
+            I[r] = rint(w.Xn[q] * c.N[m0 + r]);
+            kse[r] = (double)ks.x; snk[r] = (double)ks.y;
         } else {
-            ki = w.K[0][q];
-            I = (double)w.St[2][q];
-            kse = (double)ki; snk = (double)(w.St[0][q] - ki);
-        }
-        if (!valid) continue;
-        const double ee = ea_t * w.eb[(size_t)b * d.Mp + m];
-        const double lam0 = ee * (I + psiW * F);
-        const double rr = (lam0 + d.rate_floor) * d.dt;
-        const double em1 = expm1(-rr);
-        ll += (ki != 0 ? kse * log(-em1) : 0.0) - snk * rr;
-        if (GRAD) {
-            const double gl = d.dt * ((ki != 0 ? kse * (1.0 + em1) / (-em1) : 0.0) - snk);
-            const double ge = gl * lam0;
-            rowacc[r] = ge;
-            colacc += ge;
-            gpsi += gl * ee * Wt * F;
+            const int ki = w.K[0][q];
+            I[r] = (double)w.St[2][q];
+            kse[r] = (double)ki; snk[r] = (double)(w.St[0][q] - ki);
         }
     }
-    ll = wave_sum(ll);
-    if (GRAD) {
-        gpsi = wave_sum(gpsi);
-        colbuf[wave][lane] = colacc;
+    __syncthreads();
+    double ll = 0.0, gpsi = 0.0, colacc = 0.0;
+    double *myrow = rowbuf + (GRAD ? wave * SE_RW * SE_RS : 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double v = wave_sum(rowacc[r]);
-            if (lane == 0 && m0 + r < d.M) w.Rpart[((size_t)b * d.ntc + blockIdx.x) * d.Mp + m0 + r] = v;
+    for (int r = 0; r < SE_RW; ++r) {
+        const double ee = ea_t * eb[r];
+        const double lam0 = ee * (I[r] + psiW * F[r]);
+        const double rr = (lam0 + d.rate_floor) * d.dt;
+        double L, inv;
+        l1me_inv(rr, L, inv, ltab);
+        const bool has = kse[r] != 0.0;
+        ll += (has ? kse[r] * L : 0.0) - snk[r] * rr;
+        if (GRAD) {
+            const double gl = d.dt * ((has ? kse[r] * inv : 0.0) - snk[r]);
+            const double ge = gl * lam0;
+            myrow[r * SE_RS + lane] = ge;
+            colacc += ge;
+            gpsi += gl * ee * Wt * F[r];
         }
     }
-    if (lane == 0) { shl[wave] = ll; shp[wave] = gpsi; }
+    llbuf[wave][lane] = ll;
+    if (GRAD) {
+        psibuf[wave][lane] = gpsi;
+        colbuf[wave][lane] = colacc;
+        // row sums: lane (r = lane>>3, s = lane&7) adds the 8 entries j*8+s of row r, then the
+        // 8 lanes of a row combine by shuffles -- one LDS transpose instead of SE_RW wave reductions
+        static_assert(SE_RW == 8, "row-sum transpose assumes 8 rows per wave");
+        const int rr_ = lane >> 3, ss = lane & 7;
+        const double *src = myrow + rr_ * SE_RS + ss;
+        double v = ((src[0] + src[8]) + (src[16] + src[24])) + ((src[32] + src[40]) + (src[48] + src[56]));
+        v += __shfl_xor(v, 1, WAVE);
+        v += __shfl_xor(v, 2, WAVE);
+        v += __shfl_xor(v, 4, WAVE);
+        if (ss == 0) w.Rpart[((size_t)b * d.ntc + blockIdx.x) * d.Mp + m0 + rr_] = v;
+    }
     __syncthreads();
     const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)blockIdx.y * d.ntc + blockIdx.x;
-    if (threadIdx.x == 0) {
-        w.Lpart[tile] = shl[0] + shl[1] + shl[2] + shl[3];
-        if (GRAD) w.Ppart[tile] = shp[0] + shp[1] + shp[2] + shp[3];
-    }
-    if (GRAD && threadIdx.x < WAVE)
+    if (wave == 0) {
+        const double v = wave_sum((llbuf[0][lane] + llbuf[1][lane]) + (llbuf[2][lane] + llbuf[3][lane]));
+        if (lane == 0) w.Lpart[tile] = v;
+    } else if (GRAD && wave == 1) {
+        const double v = wave_sum((psibuf[0][lane] + psibuf[1][lane]) + (psibuf[2][lane] + psibuf[3][lane]));
+        if (lane == 0) w.Ppart[tile] = v;
+    } else if (GRAD && wave == 2) {
         w.Kpart[((size_t)b * d.nmt + blockIdx.y) * d.Tp + t] =
-            colbuf[0][lane] + colbuf[1][lane] + colbuf[2][lane] + colbuf[3][lane];
+            (colbuf[0][lane] + colbuf[1][lane]) + (colbuf[2][lane] + colbuf[3][lane]);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -372,7 +397,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
 template <bool GRAD>
 __device__ inline double reduce_chain(const Dims &d, const Consts &c, const Work &w, int b,
                                       const double *__restrict__ u, double *__restrict__ g,
-                                      double *lds_col, double *seg, double *sh) {
+                                      double *lds_col, double *seg, double *sh, const double2 *ltab) {
     const int tid = threadIdx.x;
     const double *sc = w.scal + (size_t)b * NSCAL;
     double acc = 0.0, gg0 = 0.0, gg1 = 0.0;
@@ -384,13 +409,22 @@ __device__ inline double reduce_chain(const Dims &d, const Consts &c, const Work
             const double kir = w.Kir[(size_t)b * d.Tp + t], dir = w.Dir[(size_t)b * d.Tp + t];
             const double rate = w.rir[(size_t)b * d.Tp + t];
             const double r = rate * d.dt;
-            const double em1 = expm1(-r);
-            acc += (kir != 0.0 ? kir * log(-em1) : 0.0) - dir * r;
+            double L, inv;
+            l1me_inv(r, L, inv, ltab);
+            acc += (kir != 0.0 ? kir * L : 0.0) - dir * r;
             if (GRAD) {
-                const double gr = d.dt * ((kir != 0.0 ? kir * (1.0 + em1) / (-em1) : 0.0) - dir);
+                const double gr = d.dt * ((kir != 0.0 ? kir * inv : 0.0) - dir);
                 gg0 += gr * rate;
                 gg1 += gr * rate * c.wd[t];
-                for (int ty = 0; ty < d.nmt; ++ty) col += w.Kpart[((size_t)b * d.nmt + ty) * d.Tp + t];
+                const double *kp = w.Kpart + (size_t)b * d.nmt * d.Tp + t;
+                double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+                int ty = 0;
+                for (; ty + 3 < d.nmt; ty += 4) {       // independent loads in flight
+                    c0 += kp[(size_t)ty * d.Tp]; c1 += kp[(size_t)(ty + 1) * d.Tp];
+                    c2 += kp[(size_t)(ty + 2) * d.Tp]; c3 += kp[(size_t)(ty + 3) * d.Tp];
+                }
+                for (; ty < d.nmt; ++ty) c0 += kp[(size_t)ty * d.Tp];
+                col = (c0 + c1) + (c2 + c3);
             }
         }
         if (GRAD) lds_col[t] = col;
@@ -406,24 +440,23 @@ __device__ inline double reduce_chain(const Dims &d, const Consts &c, const Work
     double csum = 0.0;
     __syncthreads();
     for (int t = t_lo; t < t_hi; ++t) csum += lds_col[t];
-    seg[tid] = csum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {             // inclusive suffix scan
-        const double v = tid + o < 256 ? seg[tid + o] : 0.0;
-        __syncthreads();
-        seg[tid] += v;
-        __syncthreads();
-    }
-    const double total = seg[0];
-    double run = tid + 1 < 256 ? seg[tid + 1] : 0.0;
+    double total;
+    double run = block_incl_suffix_scan_256(csum, seg, total) - csum;   // sum over later segments
     for (int t = t_hi - 1; t >= t_lo; --t) {
         run += lds_col[t];
         if (t >= 1) g[6 + t - 1] = run - at[t - 1] / (0.005 * 0.005);
     }
     double gsig = 0.0, gbeta = 0.0;
     for (int m = tid; m < d.M; m += 256) {
-        double R = 0.0;
-        for (int tx = 0; tx < d.ntc; ++tx) R += w.Rpart[((size_t)b * d.ntc + tx) * d.Mp + m];
+        const double *rp = w.Rpart + (size_t)b * d.ntc * d.Mp + m;
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+        int tx = 0;
+        for (; tx + 3 < d.ntc; tx += 4) {
+            r0 += rp[(size_t)tx * d.Mp]; r1 += rp[(size_t)(tx + 1) * d.Mp];
+            r2 += rp[(size_t)(tx + 2) * d.Mp]; r3 += rp[(size_t)(tx + 3) * d.Mp];
+        }
+        for (; tx < d.ntc; ++tx) r0 += rp[(size_t)tx * d.Mp];
+        const double R = (r0 + r1) + (r2 + r3);
         gsig += sp[m] * R;
         gbeta += c.la[m] * R;
         g[6 + d.T - 1 + m] = sig * R - w.Qs[(size_t)b * d.Mp + m];
@@ -454,9 +487,11 @@ __global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const 
     extern __shared__ double lds_col[];             // [Tp]
     __shared__ double sh[4];
     __shared__ double seg[256];
-    const int b = blockIdx.x;
+    __shared__ double2 ltab[LOGTAB_N];
+    const int b = d.b0 + blockIdx.x;
+    log_table_to_lds(ltab, c.logtab);
     const double lp = reduce_chain<GRAD>(d, c, w, b, u_all + (size_t)b * d.P,
-                                         GRAD ? grad + (size_t)b * d.P : nullptr, lds_col, seg, sh);
+                                         GRAD ? grad + (size_t)b * d.P : nullptr, lds_col, seg, sh, ltab);
     if (threadIdx.x == 0) {
         const double *sc = w.scal + (size_t)b * NSCAL;
         logp[b] = lp + w.constsum[b] + sc[SC_PRIOR] + sc[SC_JAC];

@@ -114,82 +114,293 @@ __global__ void k_export_events(Dims d, Work w, double *__restrict__ events, int
 // M = diag(1/var) (mcmc_kernel_factory.py:14-29; num_leapfrog_steps=16,
 // inference.py:324-329), DualAveragingStepSizeAdaptation (:32-44) and
 // DiagonalMassMatrixAdaptation (:47-60) as re-stated in DESIGN.md.
-// One workgroup per chain.  STAGE 0: first kernel of the trajectory (fresh
-// gradient at the current point, momentum draw, first half kick + drift);
-// STAGE 1: interior leapfrog; STAGE 2: last half kick, accept/reject, adaptation.
-// Every stage ends by refreshing the parameter tables for the new position.
+//
+// One 512-thread workgroup per chain.  The kernel is a latency chain, so it is
+// organised around few global-memory round trips: every thread owns at most HT
+// days and HM rows -- i.e. the alpha_t / spatial_effect entries, their momenta,
+// and the table entries ea[t], rir[t], eb[m] derived from them -- issues all its
+// loads up front, and keeps gradient, momentum and position in registers:
+//   phase 1  reduce k_se's partials  -> d/d alpha_t (suffix scan of the column sums),
+//            d/d spatial (row sums), and six block-reduced scalars
+//   phase 2  leapfrog kick/drift on the owned entries (STAGE 0 draws the momentum,
+//            STAGE 2 finishes the trajectory: accept/reject, adaptation, trace)
+//   phase 3  tables and priors for the new position (prefix scan for alpha, CAR matvec
+//            from an LDS copy of spatial_effect)
+// STAGE 0: first kernel of a trajectory; STAGE 1: interior leapfrog; STAGE 2: last.
 // ---------------------------------------------------------------------------
-template <int STAGE>
-__global__ __launch_bounds__(256) void k_hmc_step(Dims d, Consts c, Work w, SamplerCfg s, Chains ch) {
-    extern __shared__ double lds_col[];             // [Tp]
-    __shared__ double sh[4];
-    __shared__ double seg[256];
+constexpr int HB = 512;             // threads (8 waves: leaves 256 VGPRs per lane, no spills)
+constexpr int HWV = HB / WAVE;      // waves
+// HT / HM (template parameters): days / rows per thread, ceil(Tp/HB) in {1,2}, ceil(M/HB) in {1,2,4}
+constexpr int NRED = 8;
+
+// sum NV values over the block; results replicated in every thread.  sh: [HWV][NRED]
+template <int NV>
+__device__ __forceinline__ void block_sum_vec(double (&v)[NV], double *sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sh[wave * NRED + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < HWV; ++j) a += sh[j * NRED + k];
+        v[k] = a;
+    }
+}
+
+// exclusive prefix (in thread order) over the block; sh: [HWV]
+__device__ __forceinline__ double block_excl_scan_hb(double v, double *sh, double &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double inc = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    double base = 0.0, tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < HWV; ++j) { const double x = sh[j]; tot += x; if (j < wave) base += x; }
+    total = tot;
+    return base + inc - v;
+}
+
+// inclusive suffix (thread i gets sum_{j >= i}); sh: [HWV]
+__device__ __forceinline__ double block_incl_suffix_hb(double v, double *sh, double &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double inc = wave_incl_suffix_scan(v, lane);
+    __syncthreads();
+    if (lane == 0) sh[wave] = inc;
+    __syncthreads();
+    double tail = 0.0, tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < HWV; ++j) { const double x = sh[j]; tot += x; if (j > wave) tail += x; }
+    total = tot;
+    return inc + tail;
+}
+
+template <int STAGE, int HT, int HM>
+__global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, SamplerCfg s, Chains ch) {
+    extern __shared__ double lds_sp[];                 // [Mp] spatial_effect of the new position
+    __shared__ double red[HWV * NRED];
+    __shared__ double scn[HWV];
+    __shared__ double bc[12];                          // broadcast scalars
     __shared__ int s_accept;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp, *g = ch.grad + (size_t)b * d.Pp;
-    double *q0 = ch.q0 + (size_t)b * d.Pp;
-    const double *var = ch.var + (size_t)b * d.Pp;
+    __shared__ double2 ltab[LOGTAB_N];
+    const int b = d.b0 + blockIdx.x, tid = threadIdx.x;
+    const int T = d.T, M = d.M;
+    double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp, *q0 = ch.q0 + (size_t)b * d.Pp;
+    double *var = ch.var + (size_t)b * d.Pp;
     double *hs = ch.hs + (size_t)b * NHS;
-    const double *sc = w.scal + (size_t)b * NSCAL;
+    double *sc = w.scal + (size_t)b * NSCAL;
+    const int oT = 6 - 1, oM = 6 + T - 1;              // alpha_t[t-1] at oT + t ; spatial[m] at oM + m
 
-    // gradient and parameter-dependent log-prob at the current position
-    const double lik = reduce_chain<true>(d, c, w, b, q, g, lds_col, seg, sh);
-    const double lp_theta = lik + sc[SC_PRIOR] + sc[SC_JAC];
+    // ---------------- phase 0: all loads --------------------------------------
+    if (tid < LOGTAB_N) ltab[tid] = c.logtab[tid];
     const double eps = hs[HS_EPS];
-    __syncthreads();                                  // g[] visible to all threads
+    const double psi = sc[SC_PSI], sig = sc[SC_SIG], beta = sc[SC_BETA], g0 = sc[SC_G0], g1 = sc[SC_G1],
+                 a0 = sc[SC_A0], s0 = sc[SC_S0], s1 = sc[SC_S1], prior = sc[SC_PRIOR], jac = sc[SC_JAC];
+    double kir[HT], dir[HT], rate[HT], wdt[HT], col[HT], qa[HT], pa[HT], va[HT];
+    double Rm[HM], lam[HM], qs[HM], qm[HM], pm[HM], vm[HM], inN[HM];
+    const int ntile = d.nmt * d.ntc;
+    double lpart = 0.0, ppart = 0.0;
+    for (int i = tid; i < ntile; i += HB) { lpart += w.Lpart[(size_t)b * ntile + i]; ppart += w.Ppart[(size_t)b * ntile + i]; }
+#pragma unroll
+    for (int k = 0; k < HT; ++k) {
+        const int t = tid + k * HB;
+        kir[k] = dir[k] = rate[k] = wdt[k] = col[k] = qa[k] = pa[k] = 0.0; va[k] = 1.0;
+        if (t < d.Tp) {
+            kir[k] = w.Kir[(size_t)b * d.Tp + t];
+            dir[k] = w.Dir[(size_t)b * d.Tp + t];
+            rate[k] = w.rir[(size_t)b * d.Tp + t];
+            wdt[k] = c.wd[t];
+            const double *kp = w.Kpart + (size_t)b * d.nmt * d.Tp + t;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+            for (int ty0 = 0; ty0 < d.nmt; ty0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = ty0 + j < d.nmt ? kp[(size_t)(ty0 + j) * d.Tp] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) { c0 += v[j]; c1 += v[j + 1]; c2 += v[j + 2]; c3 += v[j + 3]; }
+            }
+            col[k] = (c0 + c1) + (c2 + c3);
+            if (t >= 1 && t < T) { qa[k] = q[oT + t]; pa[k] = STAGE == 0 ? 0.0 : p[oT + t]; va[k] = var[oT + t]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HM; ++k) {
+        const int m = tid + k * HB;
+        Rm[k] = lam[k] = qs[k] = qm[k] = pm[k] = inN[k] = 0.0; vm[k] = 1.0;
+        if (m < M) {
+            const double *rp = w.Rpart + (size_t)b * d.ntc * d.Mp + m;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+            for (int tx0 = 0; tx0 < d.ntc; tx0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = tx0 + j < d.ntc ? rp[(size_t)(tx0 + j) * d.Mp] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) { r0 += v[j]; r1 += v[j + 1]; r2 += v[j + 2]; r3 += v[j + 3]; }
+            }
+            Rm[k] = (r0 + r1) + (r2 + r3);
+            lam[k] = c.la[m];
+            inN[k] = c.invN[m];
+            qs[k] = w.Qs[(size_t)b * d.Mp + m];
+            qm[k] = q[oM + m]; pm[k] = STAGE == 0 ? 0.0 : p[oM + m]; vm[k] = var[oM + m];
+        }
+    }
+    double q6[6], p6[6], v6[6];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { q6[i] = q[i]; p6[i] = STAGE == 0 ? 0.0 : p[i]; v6[i] = var[i]; }
+    }
+    __syncthreads();                                   // ltab
 
+    // ---------------- phase 1: gradient at the current position ---------------
+    double rv[6] = {lpart, 0.0, 0.0, 0.0, 0.0, ppart};  // lik, gg0, gg1, gsig, gbeta, gpsi
+#pragma unroll
+    for (int k = 0; k < HT; ++k) {
+        const int t = tid + k * HB;
+        if (t < T) {
+            const double r = rate[k] * d.dt;
+            double L, inv;
+            l1me_inv(r, L, inv, ltab);
+            rv[0] += (kir[k] != 0.0 ? kir[k] * L : 0.0) - dir[k] * r;
+            const double gr = d.dt * ((kir[k] != 0.0 ? kir[k] * inv : 0.0) - dir[k]);
+            rv[1] += gr * rate[k];
+            rv[2] += gr * rate[k] * wdt[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HM; ++k) {
+        rv[3] += qm[k] * Rm[k];
+        rv[4] += lam[k] * Rm[k];
+    }
+    block_sum_vec<6>(rv, red);
+    const double lp_theta = rv[0] + prior + jac;
+    // d/d alpha_t[t-1] = sum_{t' >= t} col[t']: suffix scan, chunks from the back
+    double ga[HT], gtot = 0.0;
+    {
+        double tail = 0.0;
+#pragma unroll
+        for (int k = HT - 1; k >= 0; --k) {
+            double tot;
+            ga[k] = block_incl_suffix_hb(col[k], scn, tot) + tail;
+            tail += tot;
+        }
+        gtot = tail;
+    }
+#pragma unroll
+    for (int k = 0; k < HT; ++k) {
+        const int t = tid + k * HB;
+        ga[k] = (t >= 1 && t < T) ? ga[k] - qa[k] / (0.005 * 0.005) : 0.0;   // + prior gradient; t=0 owns no alpha_t
+    }
+    double gm[HM];
+#pragma unroll
+    for (int k = 0; k < HM; ++k) gm[k] = sig * Rm[k] - qs[k];
+    double g6[6];
+    g6[0] = (rv[5] + 2.0 / psi - 10.0) * s0 + (1.0 - s0);
+    g6[1] = (rv[3] - sig / 0.01) * s1 + (1.0 - s1);
+    g6[2] = rv[4] - beta;
+    g6[3] = rv[1] - g0 / 1.0e4;
+    g6[4] = rv[2] - g1 / 1.0e4;
+    g6[5] = gtot - a0 / 100.0;
+
+    // ---------------- phase 2: leapfrog on the owned entries -------------------
+    double kin = 0.0;                                   // kinetic energy contribution (STAGE 0: start, 2: end)
     if (STAGE == 0) {
         const RngKey key = rng_key(s, ch, b);
-        double k0 = 0.0;
-        for (int i2 = tid; i2 * 2 < d.P; i2 += 256) {
+        auto draw = [&](int i) {                       // standard normal of component i (pairs share a Philox call)
             double u1, u2;
-            rng_uniform2(key, RS_MOMENTUM, (uint32_t)i2, u1, u2);
+            rng_uniform2(key, RS_MOMENTUM, (uint32_t)(i >> 1), u1, u2);
             const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
-            const double z[2] = {rad * cos(ang), rad * sin(ang)};
+            return (i & 1) ? rad * sin(ang) : rad * cos(ang);
+        };
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = i2 * 2 + j;
-                if (i >= d.P) break;
-                const double v = var[i];
-                double pi = z[j] / sqrt(v);           // p ~ N(0, diag(1/var))
-                k0 += 0.5 * v * pi * pi;
-                q0[i] = q[i];
-                pi += 0.5 * eps * g[i];
-                p[i] = pi;
-                q[i] += eps * v * pi;
+        for (int k = 0; k < HT; ++k) {
+            const int t = tid + k * HB;
+            if (t >= 1 && t < T) {
+                double pi = draw(oT + t) / sqrt(va[k]);
+                kin += 0.5 * va[k] * pi * pi;
+                q0[oT + t] = qa[k];
+                pi += 0.5 * eps * ga[k];
+                pa[k] = pi;
+                qa[k] += eps * va[k] * pi;
             }
         }
-        k0 = block_sum_256(k0, sh);
-        if (tid == 0) { hs[HS_LP0] = lp_theta; hs[HS_K0] = k0; }
-    } else if (STAGE == 1) {
-        for (int i = tid; i < d.P; i += 256) {
-            const double pi = p[i] + eps * g[i];
-            p[i] = pi;
-            q[i] += eps * var[i] * pi;
+#pragma unroll
+        for (int k = 0; k < HM; ++k) {
+            const int m = tid + k * HB;
+            if (m < M) {
+                double pi = draw(oM + m) / sqrt(vm[k]);
+                kin += 0.5 * vm[k] * pi * pi;
+                q0[oM + m] = qm[k];
+                pi += 0.5 * eps * gm[k];
+                pm[k] = pi;
+                qm[k] += eps * vm[k] * pi;
+            }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double pi = draw(i) / sqrt(v6[i]);
+                kin += 0.5 * v6[i] * pi * pi;
+                q0[i] = q6[i];
+                pi += 0.5 * eps * g6[i];
+                p6[i] = pi;
+                q6[i] += eps * v6[i] * pi;
+            }
         }
     } else {
-        double k1 = 0.0;
-        for (int i = tid; i < d.P; i += 256) {
-            const double pi = p[i] + 0.5 * eps * g[i];
-            p[i] = pi;
-            k1 += 0.5 * var[i] * pi * pi;
+        const double kick = STAGE == 1 ? eps : 0.5 * eps;
+#pragma unroll
+        for (int k = 0; k < HT; ++k) {
+            pa[k] += kick * ga[k];
+            if (STAGE == 1) qa[k] += eps * va[k] * pa[k];
+            else kin += 0.5 * va[k] * pa[k] * pa[k];
         }
-        k1 = block_sum_256(k1, sh);
+#pragma unroll
+        for (int k = 0; k < HM; ++k) {
+            pm[k] += kick * gm[k];
+            if (STAGE == 1) qm[k] += eps * vm[k] * pm[k];
+            else kin += 0.5 * vm[k] * pm[k] * pm[k];
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                p6[i] += kick * g6[i];
+                if (STAGE == 1) q6[i] += eps * v6[i] * p6[i];
+                else kin += 0.5 * v6[i] * p6[i] * p6[i];
+            }
+        }
+    }
+    bool accepted = true;
+    if (STAGE != 1) {
+        double kv[1] = {kin};
+        block_sum_vec<1>(kv, red);
+        kin = kv[0];
+    }
+    if (STAGE == 0 && tid == 0) { hs[HS_LP0] = lp_theta; hs[HS_K0] = kin; }
+    if (STAGE == 2) {
         if (tid == 0) {
             const RngKey key = rng_key(s, ch, b);
             double u1, u2;
             rng_uniform2(key, RS_HMC_ACCEPT, 0u, u1, u2);
-            const double log_ratio = (lp_theta - hs[HS_LP0]) - (k1 - hs[HS_K0]);
-            const int acc = log(u1) < log_ratio ? 1 : 0;      // NaN compares false -> reject
+            const double lp0 = hs[HS_LP0];
+            const double log_ratio = (lp_theta - lp0) - (kin - hs[HS_K0]);
+            const int acc = log(u1) < log_ratio ? 1 : 0;          // NaN compares false -> reject
             s_accept = acc;
             hs[HS_ACC] = (double)acc;
             hs[HS_LOGACC] = log_ratio;
-            hs[HS_LP_THETA] = acc ? lp_theta : hs[HS_LP0];
+            const double lpt = acc ? lp_theta : lp0;
+            hs[HS_LP_THETA] = lpt;
             const unsigned slot = ch.sweep[b] - ch.slot0[0];
             if (slot < (unsigned)s.cap) {
                 double *tr = ch.tr_hmc + ((size_t)slot * s.B + b) * 3;
                 tr[0] = (double)acc;
-                tr[1] = hs[HS_LP_THETA] + hs[HS_LP_CONST];
+                tr[1] = lpt + hs[HS_LP_CONST];
                 tr[2] = eps;
             }
             if (s.adapt_step) {                       // dual averaging (Hoffman & Gelman alg. 5, TFP defaults)
@@ -206,41 +417,135 @@ __global__ __launch_bounds__(256) void k_hmc_step(Dims d, Consts c, Work w, Samp
             }
         }
         __syncthreads();
-        const bool acc = s_accept != 0;
-        if (!acc)
-            for (int i = tid; i < d.P; i += 256) q[i] = q0[i];
+        accepted = s_accept != 0;
+        if (!accepted) {                              // back to the start of the trajectory
+#pragma unroll
+            for (int k = 0; k < HT; ++k) { const int t = tid + k * HB; if (t >= 1 && t < T) qa[k] = q0[oT + t]; }
+#pragma unroll
+            for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; if (m < M) qm[k] = q0[oM + m]; }
+            if (tid == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) q6[i] = q0[i];
+            }
+        }
         if (s.adapt_mass) {                           // Welford update with the new state (ddof 0)
             const double n1 = hs[HS_RV_N] + 1.0;
             double *mean = ch.rv_mean + (size_t)b * d.Pp, *m2 = ch.rv_m2 + (size_t)b * d.Pp;
-            double *varw = ch.var + (size_t)b * d.Pp;
-            for (int i = tid; i < d.P; i += 256) {
-                const double x = acc ? q[i] : q0[i];
+            auto upd = [&](int i, double x) {
                 const double dlt = x - mean[i];
                 const double mu = mean[i] + dlt / n1;
                 const double ss = m2[i] + dlt * (x - mu);
                 mean[i] = mu; m2[i] = ss;
-                varw[i] = ss / n1;
+                var[i] = ss / n1;
+            };
+#pragma unroll
+            for (int k = 0; k < HT; ++k) { const int t = tid + k * HB; if (t >= 1 && t < T) upd(oT + t, qa[k]); }
+#pragma unroll
+            for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; if (m < M) upd(oM + m, qm[k]); }
+            if (tid == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) upd(i, q6[i]);
             }
             __syncthreads();
             if (tid == 0) hs[HS_RV_N] = n1;
         }
     }
-    __syncthreads();
-    param_tables(d, c, w, b, q, seg, sh);
-    if (STAGE == 2 && tid == 0) {
+    // write back position / momentum
+#pragma unroll
+    for (int k = 0; k < HT; ++k) {
+        const int t = tid + k * HB;
+        if (t >= 1 && t < T) { q[oT + t] = qa[k]; if (STAGE != 2) p[oT + t] = pa[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < HM; ++k) {
+        const int m = tid + k * HB;
+        if (m < M) { q[oM + m] = qm[k]; if (STAGE != 2) p[oM + m] = pm[k]; lds_sp[m] = qm[k]; }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { q[i] = q6[i]; if (STAGE != 2) p[i] = p6[i]; }
+        const double e0 = 2.220446049250313e-16;
+        bc[0] = softplus(q6[0]) + e0; bc[1] = softplus(q6[1]) + e0;
+        bc[2] = q6[2]; bc[3] = q6[3]; bc[4] = q6[4]; bc[5] = q6[5];
+        bc[6] = q6[0]; bc[7] = q6[1];
+    }
+    __syncthreads();                                   // bc, lds_sp
+
+    // ---------------- phase 3: tables and priors at the new position -----------
+    const double npsi = bc[0], nsig = bc[1], nbeta = bc[2], ng0 = bc[3], ng1 = bc[4], na0 = bc[5];
+    double pr[2] = {0.0, 0.0};                         // sum alpha_t^2, s' Q s
+    {
+        double carry = na0;
+#pragma unroll
+        for (int k = 0; k < HT; ++k) {
+            const int t = tid + k * HB;
+            const double v = (t >= 1 && t < T) ? qa[k] : 0.0;
+            double tot;
+            const double acc = carry + block_excl_scan_hb(v, scn, tot) + v;   // alpha_0 + cumsum(alpha_t)[t-1]
+            carry += tot;
+            pr[0] += v * v;
+            if (t < T) {
+                w.ea[(size_t)b * d.Tp + t] = exp(acc);
+                w.rir[(size_t)b * d.Tp + t] = exp(ng0 + ng1 * wdt[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HM; ++k) {
+        const int m = tid + k * HB;
+        if (m < M) {
+            w.eb[(size_t)b * d.Mp + m] = exp(nbeta * lam[k] + nsig * qm[k]) * inN[k];
+            double acc = 0.0;
+            if (c.qw > 0) {
+                for (int e0 = 0; e0 < c.qw; e0 += 8) {
+                    double qv[8]; int qc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool on = e0 + j < c.qw;
+                        qv[j] = on ? c.Qell_val[(size_t)(e0 + j) * d.Mp + m] : 0.0;
+                        qc[j] = on ? c.Qell_col[(size_t)(e0 + j) * d.Mp + m] : 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += qv[j] * lds_sp[qc[j]];
+                }
+            } else {
+                for (int e = c.Qrow[m]; e < c.Qrow[m + 1]; ++e) acc += c.Qval[e] * lds_sp[c.Qcol[e]];
+            }
+            w.Qs[(size_t)b * d.Mp + m] = acc;
+            pr[1] += qm[k] * acc;
+        }
+    }
+    block_sum_vec<2>(pr, red);
+    if (tid == 0) {
+        // model_spec.py:140-198; the parameter-free normalisers are folded into d.prior_const
+        double lp = d.prior_const;
+        lp += -0.5 * na0 * na0 / 100.0 - 0.5 * nbeta * nbeta;
+        lp += 2.0 * log(npsi) - 10.0 * npsi;
+        lp += -0.5 * pr[0] / (0.005 * 0.005);
+        lp += -nsig * nsig / 0.02;
+        lp += -0.5 * pr[1];
+        lp += -0.5 * (ng0 * ng0 + ng1 * ng1) / 1.0e4;
+        sc[SC_PSI] = npsi; sc[SC_SIG] = nsig; sc[SC_BETA] = nbeta; sc[SC_G0] = ng0; sc[SC_G1] = ng1;
+        sc[SC_A0] = na0;
+        const double ls0 = -softplus(-bc[6]), ls1 = -softplus(-bc[7]);
+        sc[SC_S0] = exp(ls0); sc[SC_S1] = exp(ls1);
+        sc[SC_PRIOR] = lp;
+        sc[SC_JAC] = ls0 + ls1;
+    }
+    if (STAGE == 2) {
         // constrained draw -> trace (param_bijector.inverse(draws[0]), inference.py:375)
         const unsigned slot = ch.sweep[b] - ch.slot0[0];
         if (slot < (unsigned)s.cap) {
             double *tr = ch.tr_theta + ((size_t)slot * s.B + b) * d.P;
-            tr[0] = sc[SC_PSI];
-            tr[1] = sc[SC_SIG];
-        }
-    }
-    if (STAGE == 2) {
-        const unsigned slot = ch.sweep[b] - ch.slot0[0];
-        if (slot < (unsigned)s.cap) {
-            double *tr = ch.tr_theta + ((size_t)slot * s.B + b) * d.P;
-            for (int i = 2 + tid; i < d.P; i += 256) tr[i] = q[i];
+#pragma unroll
+            for (int k = 0; k < HT; ++k) { const int t = tid + k * HB; if (t >= 1 && t < T) tr[oT + t] = qa[k]; }
+#pragma unroll
+            for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; if (m < M) tr[oM + m] = qm[k]; }
+            if (tid == 0) {
+                tr[0] = npsi; tr[1] = nsig;
+#pragma unroll
+                for (int i = 2; i < 6; ++i) tr[i] = q6[i];
+            }
         }
     }
 }
@@ -251,8 +556,10 @@ __global__ __launch_bounds__(256) void k_chain_refresh(Dims d, Consts c, Work w,
     extern __shared__ double lds_col[];
     __shared__ double sh[4];
     __shared__ double seg[256];
-    const int b = blockIdx.x;
-    const double lik = reduce_chain<false>(d, c, w, b, ch.q + (size_t)b * d.Pp, nullptr, lds_col, seg, sh);
+    __shared__ double2 ltab[LOGTAB_N];
+    const int b = d.b0 + blockIdx.x;
+    log_table_to_lds(ltab, c.logtab);
+    const double lik = reduce_chain<false>(d, c, w, b, ch.q + (size_t)b * d.Pp, nullptr, lds_col, seg, sh, ltab);
     if (threadIdx.x == 0) {
         const double *sc = w.scal + (size_t)b * NSCAL;
         ch.hs[(size_t)b * NHS + HS_LP_THETA] = lik + sc[SC_PRIOR] + sc[SC_JAC];
@@ -263,7 +570,7 @@ __global__ __launch_bounds__(256) void k_chain_refresh(Dims d, Consts c, Work w,
 __global__ __launch_bounds__(256) void k_chain_tables(Dims d, Consts c, Work w, Chains ch) {
     __shared__ double sh[4];
     __shared__ double seg[256];
-    param_tables(d, c, w, blockIdx.x, ch.q + (size_t)blockIdx.x * d.Pp, seg, sh);
+    param_tables(d, c, w, d.b0 + blockIdx.x, ch.q + (size_t)(d.b0 + blockIdx.x) * d.Pp, seg, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -299,27 +606,21 @@ __device__ inline int block_min_int(int v, int *sh) {
 }
 
 // Index of the r-th (0-based) element with flag set among n elements, where
-// element i's flag is flag(i).  Each thread owns a contiguous segment.
+// element i's flag is flag(i).  Each thread owns a contiguous segment; the
+// prefix counts come from wave shuffles (3 barriers in all).
 // Returns -1 if r >= count.  `count_out` receives the number of set flags.
 template <typename FlagFn>
-__device__ inline int block_select(int n, int r, FlagFn flag, int *cnt_sh /*[256]*/, int *res_sh, int &count_out) {
+__device__ inline int block_select(int n, int r, FlagFn flag, int *cnt_sh /*[>=4]*/, int *res_sh, int &count_out) {
     const int tid = threadIdx.x;
     const int per = (n + 255) / 256;
     const int lo = tid * per, hi = min(n, lo + per);
     int c = 0;
     for (int i = lo; i < hi; ++i) c += flag(i) ? 1 : 0;
-    __syncthreads();
-    cnt_sh[tid] = c;
+    int total;
+    const int before = block_excl_scan_256(c, cnt_sh, total);
+    count_out = total;
     if (tid == 0) *res_sh = -1;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = tid >= o ? cnt_sh[tid - o] : 0;
-        __syncthreads();
-        cnt_sh[tid] += v;
-        __syncthreads();
-    }
-    const int before = tid ? cnt_sh[tid - 1] : 0;
-    count_out = cnt_sh[255];
     if (r >= before && r < before + c) {
         int k = r - before;
         for (int i = lo; i < hi; ++i)
@@ -502,76 +803,98 @@ __device__ inline void propose(const Dims &d, const Work &w, const SamplerCfg &s
 // Per-cell log-likelihood pieces: th = parameter dependent (S->E and I->R
 // rates), cn = parameter free (binomial coefficients + E->I term).
 __device__ inline void cell_terms(const Dims &d, double S, double E, double I, double kse, double kei, double kir,
-                                  double F, double ee, double psiW, double r_ir, double L_ei, double r_ei,
-                                  double &th, double &cn) {
-    cn = lbinom(S, kse) + lbinom(E, kei) + lbinom(I, kir) + kei * L_ei - (E - kei) * r_ei;
+                                  double F, double ee, double psiW, double r_ir, double L_ir, double L_ei,
+                                  double r_ei, const double2 *ltab, double &th, double &cn) {
+    cn = lbinom(S, kse, ltab) + lbinom(E, kei, ltab) + lbinom(I, kir, ltab) + kei * L_ei - (E - kei) * r_ei;
     const double rr = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
-    th = (kse != 0.0 ? kse * log1mexp(rr) : 0.0) - (S - kse) * rr;
-    th += (kir != 0.0 ? kir * log1mexp(r_ir) : 0.0) - (I - kir) * r_ir;
+    th = (kse != 0.0 ? kse * log1mexp(rr, ltab) : 0.0) - (S - kse) * rr;
+    th += (kir != 0.0 ? kir * L_ir : 0.0) - (I - kir) * r_ir;
 }
 
 // k_move_delta: log-likelihood change of the pending proposal, over the cells it touches.
-// grid (nrb_d, B); wave = one row at a time, lanes over the days of the hull.
+// grid (nrb_d, B).  Rows that only see a changed F (E->I moves): one wave per row, lanes
+// over the days of the hull.  The (<= m) rows whose own state changes carry the expensive
+// binomial-coefficient terms, so the whole workgroup spreads over that row's days.
 __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf) {
     __shared__ Move mv;
     __shared__ double sh_th[4], sh_cn[4];
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double2 ltab[LOGTAB_N];
+    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) mv = ch.mv[(size_t)buf * s.B + b];
-    __syncthreads();
+    log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes mv
     double dth = 0.0, dcn = 0.0;
     if (mv.valid && mv.n > 0) {
         const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
-        const double r_ei = d.nu * d.dt, L_ei = log1mexp(r_ei);
+        const double r_ei = d.nu * d.dt, L_ei = d.L_ei;
         const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
         const int r_lo = blockIdx.x * rows_per_blk, r_hi = min(d.M, r_lo + rows_per_blk);
-        for (int j = r_lo + wave; j < r_hi; j += 4) {
-            bool mine = false;
+        const double *ea = w.ea + (size_t)b * d.Tp;
+        if (mv.any_dI) {
+            for (int j = r_lo + wave; j < r_hi; j += 4) {
+                bool mine = false;
 #pragma unroll
-            for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == j);
-            if (!mine && !mv.any_dI) continue;       // wave-uniform
+                for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == j);
+                if (mine) continue;                  // wave-uniform
+                const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
+                const double eb = w.eb[(size_t)b * d.Mp + j];
+                double coef[MMAX];
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)      // Cstar is symmetric: read row m_i contiguously
+                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                                       : 0.0;
+                for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
+                    double dF = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MMAX; ++i)
+                        if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+                    if (dF == 0.0) continue;
+                    const double S = w.St[0][rowoff + t], I = w.St[2][rowoff + t], kse = w.K[0][rowoff + t];
+                    const double F = w.F[rowoff + t];
+                    const double ee = ea[t] * eb, psiW = psi * c.W[t];
+                    const double r0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
+                    const double r1 = (ee * (I + psiW * (F + dF)) + d.rate_floor) * d.dt;
+                    dth += (kse != 0.0 ? kse * (log1mexp(r1, ltab) - log1mexp(r0, ltab)) : 0.0) - (S - kse) * (r1 - r0);
+                }
+            }
+        }
+        for (int i0 = 0; i0 < mv.n; ++i0) {
+            const int j = mv.m[i0];
+            if (j < r_lo || j >= r_hi) continue;     // block-uniform
             const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
             const double eb = w.eb[(size_t)b * d.Mp + j];
             double coef[MMAX];
 #pragma unroll
-            for (int i = 0; i < MMAX; ++i)          // Cstar is symmetric: read row m_i contiguously
+            for (int i = 0; i < MMAX; ++i)
                 coef[i] = (i < mv.n && mv.tgt == 1)
                               ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
                               : 0.0;
-            for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
-                int dS = 0, dE = 0, dI = 0, dkt = 0;
+            for (int t = mv.LO + (int)threadIdx.x; t <= mv.HI; t += 256) {
                 double dF = 0.0;
 #pragma unroll
-                for (int i = 0; i < MMAX; ++i) {
-                    if (i >= mv.n) break;
-                    const bool in_state = t > mv.lo[i] && t <= mv.hi[i];
-                    if (in_state) dF += coef[i];
-                    if (mv.m[i] != j) continue;
-                    if (in_state) {
-                        if (mv.tgt == 0) { dS += mv.dsrc[i]; dE -= mv.dsrc[i]; }
-                        else { dE += mv.dsrc[i]; dI -= mv.dsrc[i]; }
-                    }
-                    if (t == mv.a[i]) dkt += mv.dka[i];
-                    if (t == mv.b[i]) dkt += mv.dkb[i];
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+                const bool in_state = t > mv.lo[i0] && t <= mv.hi[i0];
+                int dS = 0, dE = 0, dI = 0, dkt = 0;
+                if (in_state) {
+                    if (mv.tgt == 0) { dS = mv.dsrc[i0]; dE = -mv.dsrc[i0]; }
+                    else { dE = mv.dsrc[i0]; dI = -mv.dsrc[i0]; }
                 }
+                if (t == mv.a[i0]) dkt += mv.dka[i0];
+                if (t == mv.b[i0]) dkt += mv.dkb[i0];
                 if (dS == 0 && dE == 0 && dI == 0 && dkt == 0 && dF == 0.0) continue;
                 const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
                 const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
                 const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
                 const double F = w.F[rowoff + t];
-                const double ee = w.ea[(size_t)b * d.Tp + t] * eb, psiW = psi * c.W[t];
+                const double ee = ea[t] * eb, psiW = psi * c.W[t];
                 const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
-                if (mine) {
-                    double th0, cn0, th1, cn1;
-                    cell_terms(d, S, E, I, kse, kei, kir, F, ee, psiW, r_ir, L_ei, r_ei, th0, cn0);
-                    cell_terms(d, S + dS, E + dE, I + dI, kse + dk0, kei + dk1, kir, F + dF, ee, psiW, r_ir,
-                               L_ei, r_ei, th1, cn1);
-                    dth += th1 - th0;
-                    dcn += cn1 - cn0;
-                } else {
-                    const double r0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
-                    const double r1 = (ee * (I + psiW * (F + dF)) + d.rate_floor) * d.dt;
-                    dth += (kse != 0.0 ? kse * (log1mexp(r1) - log1mexp(r0)) : 0.0) - (S - kse) * (r1 - r0);
-                }
+                const double L_ir = log1mexp(r_ir, ltab);
+                double th0, cn0, th1, cn1;
+                cell_terms(d, S, E, I, kse, kei, kir, F, ee, psiW, r_ir, L_ir, L_ei, r_ei, ltab, th0, cn0);
+                cell_terms(d, S + dS, E + dE, I + dI, kse + dk0, kei + dk1, kir, F + dF, ee, psiW, r_ir, L_ir, L_ei,
+                           r_ei, ltab, th1, cn1);
+                dth += th1 - th0;
+                dcn += cn1 - cn0;
             }
         }
     }
@@ -597,16 +920,18 @@ __global__ __launch_bounds__(256) void k_move_pa(Dims d, Consts c, Work w, Sampl
     __shared__ int cnt_sh[256];
     __shared__ int ish[4];
     __shared__ int s_acc;
-    __shared__ double s_dth, s_dcn;
-    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ double s_dth, s_dcn, shd[4];
+    const int b = d.b0 + blockIdx.y, tid = threadIdx.x;
     if (have_prev) {
+        if (tid == 0) mv = ch.mv[(size_t)pbuf * s.B + b];
+        double dth = 0.0, dcn = 0.0;
+        for (int i = tid; i < s.nrb_d; i += 256) {
+            dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
+            dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
+        }
+        dth = block_sum_256(dth, shd);
+        dcn = block_sum_256(dcn, shd);
         if (tid == 0) {
-            mv = ch.mv[(size_t)pbuf * s.B + b];
-            double dth = 0.0, dcn = 0.0;
-            for (int i = 0; i < s.nrb_d; ++i) {
-                dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
-                dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
-            }
             const double ratio = dth + dcn + mv.logq;
             s_acc = (mv.valid && mv.logu < ratio) ? 1 : 0;   // NaN -> reject
             s_dth = dth; s_dcn = dcn;
@@ -674,7 +999,7 @@ __global__ __launch_bounds__(256) void k_move_pa(Dims d, Consts c, Work w, Sampl
 // End of sweep: record the event tensor in the reference's [M][T][3] order and
 // advance the sweep counter.  grid (blocks, B).
 __global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Chains ch) {
-    const int b = blockIdx.y;
+    const int b = d.b0 + blockIdx.y;
     const unsigned slot = ch.sweep[b] - ch.slot0[0];
     if (slot < (unsigned)s.cap) {
         int *out = ch.tr_events + ((size_t)slot * s.B + b) * d.M * d.T * 3;
@@ -689,9 +1014,9 @@ __global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Ch
     }
 }
 
-__global__ void k_advance(Chains ch, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) ch.sweep[b] += 1;
+__global__ void k_advance(Chains ch, int b0, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) ch.sweep[b0 + i] += 1;
 }
 
 }  // namespace seir

@@ -4,6 +4,7 @@
 // this file: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -91,16 +92,28 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
     const int M = ds->M, T = ds->T, B = ds->max_chains;
     Dims &d = ctx->d;
     d.M = M; d.T = T;
-    d.Mp = ceil_to(M, 16);
+    d.Mp = ceil_to(M, 64);
     d.Tp = ceil_to(T, 64);
     d.Kp = ceil_to(M, 4);
     d.P = 6 + (T - 1) + M;
     d.Pp = d.P;
+    d.b0 = 0;
     d.nrb_scan = (M + SCAN_ROWS - 1) / SCAN_ROWS;
     d.nmt = d.Mp / SE_TM;
     d.ntc = d.Tp / 64;
     d.nu = ds->nu; d.dt = ds->time_delta; d.rate_floor = ds->rate_floor;
     d.car_half_logdet = ds->car_half_logdet;
+    {   // constants of the prior log-densities, model_spec.py:140-198 (TFP formulas)
+        const double L2PI = 1.8378770664093453;
+        d.prior_const = (-std::log(10.0) - 0.5 * L2PI)                       // alpha_0
+                        + (-0.5 * L2PI)                                        // beta_area
+                        + (3.0 * std::log(10.0) - std::lgamma(3.0))            // psi
+                        - (T - 1) * (std::log(0.005) + 0.5 * L2PI)             // alpha_t
+                        + (0.5 * std::log(2.0 / M_PI) - std::log(0.1))         // sigma_space
+                        + (ds->car_half_logdet - 0.5 * M * L2PI)               // spatial_effect
+                        + 2.0 * (-std::log(100.0) - 0.5 * L2PI);               // gamma0, gamma1
+    }
+    d.L_ei = std::log(-std::expm1(-ds->nu * ds->time_delta));
     ctx->Bmax = B;
     ctx->device = ds->device;
 
@@ -140,7 +153,34 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
         qrow[m + 1] = (int)qcol.size();
     }
     if (qcol.empty()) { qcol.push_back(0); qval.push_back(0.0); }
+    // table of device_math.h fast_log: c_i = 1 + (i + 1/2)/128, (fl(1/c_i), -log(fl(1/c_i)))
+    std::vector<double2> ltab(LOGTAB_N);
+    for (int i = 0; i < LOGTAB_N; ++i) {
+        const long double cc = 1.0L + ((long double)i + 0.5L) / (long double)LOGTAB_N;
+        const double invc = (double)(1.0L / cc);
+        ltab[i].x = invc;
+        ltab[i].y = (double)(-logl((long double)invc));
+    }
     int rc;
+    if ((rc = dev_upload(ctx, &ctx->c.logtab, ltab))) return rc;
+    {   // ELL copy of car_Q (adjacency rows are short): [k][m] so that a wave reads coalesced
+        int qw = 0;
+        for (int m = 0; m < M; ++m) qw = std::max(qw, qrow[m + 1] - qrow[m]);
+        if (qw <= 32) {
+            std::vector<int> ec((size_t)std::max(qw, 1) * d.Mp, 0);
+            std::vector<double> ev((size_t)std::max(qw, 1) * d.Mp, 0.0);
+            for (int m = 0; m < M; ++m)
+                for (int e = qrow[m], k = 0; e < qrow[m + 1]; ++e, ++k) {
+                    ec[(size_t)k * d.Mp + m] = qcol[e];
+                    ev[(size_t)k * d.Mp + m] = qval[e];
+                }
+            ctx->c.qw = qw;
+            if ((rc = dev_upload(ctx, &ctx->c.Qell_col, ec))) return rc;
+            if ((rc = dev_upload(ctx, &ctx->c.Qell_val, ev))) return rc;
+        } else {
+            ctx->c.qw = 0;
+        }
+    }
     if ((rc = dev_upload(ctx, &ctx->c.Cstar, Cs))) return rc;
     if ((rc = dev_upload(ctx, &ctx->c.N, N))) return rc;
     if ((rc = dev_upload(ctx, &ctx->c.invN, invN))) return rc;
@@ -186,7 +226,8 @@ extern "C" int seir_create(const seir_desc *ds, seir_ctx **out) {
     if (ds->M < 1 || ds->T < 1 || ds->max_chains < 1)
         return fail(SEIR_ERR_INVALID, "M, T and max_chains must be >= 1 (got %d, %d, %d)", ds->M, ds->T,
                     ds->max_chains);
-    if (ds->T > 2048) return fail(SEIR_ERR_INVALID, "T=%d exceeds the supported 2048 days", ds->T);
+    if (ds->T > 2048 || ds->M > 2048)
+        return fail(SEIR_ERR_INVALID, "M=%d, T=%d exceed the supported 2048 x 2048", ds->M, ds->T);
     if (!ds->Cstar || !ds->N || !ds->W || !ds->weekday_c || !ds->log_area_c || !ds->car_Q || !ds->init_state)
         return fail(SEIR_ERR_INVALID, "null covariate pointer");
     if (!(ds->time_delta > 0.0) || !(ds->nu > 0.0))
@@ -209,50 +250,52 @@ static int check_batch(seir_ctx *ctx, int B) {
 }
 
 // --- individual launches ---------------------------------------------------
+// `d.b0` selects the first chain, `nb` the number of chains, `st` the stream.
+struct LaunchCfg { Dims d; hipStream_t st; int nb; };
+static LaunchCfg whole(seir_ctx *ctx, int B) { return LaunchCfg{ctx->d, ctx->stream, B}; }
+
 template <int SRC>
-static void launch_scan(seir_ctx *ctx, int B, const double *events) {
-    const Dims &d = ctx->d;
-    hipLaunchKernelGGL(k_scan<SRC>, dim3(d.nrb_scan, B), dim3(256), (size_t)4 * d.Tp * 2 * sizeof(double),
-                       ctx->stream, d, ctx->c, ctx->w, events);
+static void launch_scan(seir_ctx *ctx, const LaunchCfg &l, const double *events) {
+    const Dims &d = l.d;
+    hipLaunchKernelGGL(k_scan<SRC>, dim3(d.nrb_scan, l.nb), dim3(256), (size_t)4 * d.Tp * 2 * sizeof(double),
+                       l.st, d, ctx->c, ctx->w, events);
 }
-static void launch_colreduce(seir_ctx *ctx, int B) {
-    hipLaunchKernelGGL(k_colreduce, dim3(B), dim3(256), 0, ctx->stream, ctx->d, ctx->w);
+static void launch_colreduce(seir_ctx *ctx, const LaunchCfg &l) {
+    hipLaunchKernelGGL(k_colreduce, dim3(l.nb), dim3(256), 0, l.st, l.d, ctx->w);
 }
-static void launch_gemm(seir_ctx *ctx, int B) {
-    const Dims &d = ctx->d;
+static void launch_gemm(seir_ctx *ctx, const LaunchCfg &l) {
+    const Dims &d = l.d;
     const int ntt = d.Tp / 16, per_wg = 4 * GEMM_TT;
-    hipLaunchKernelGGL(k_gemm, dim3((ntt + per_wg - 1) / per_wg, d.Mp / 16, B), dim3(256),
-                       (size_t)16 * gemm_lda(d.Kp) * sizeof(double), ctx->stream, d, ctx->c, ctx->w);
+    hipLaunchKernelGGL(k_gemm, dim3((ntt + per_wg - 1) / per_wg, d.Mp / 16, l.nb), dim3(256),
+                       (size_t)16 * gemm_lda(d.Kp) * sizeof(double), l.st, d, ctx->c, ctx->w);
 }
-static void launch_params(seir_ctx *ctx, int B, const double *u) {
-    hipLaunchKernelGGL(k_params, dim3(B), dim3(256), 0, ctx->stream, ctx->d, ctx->c, ctx->w, u);
+static void launch_params(seir_ctx *ctx, const LaunchCfg &l, const double *u) {
+    hipLaunchKernelGGL(k_params, dim3(l.nb), dim3(256), 0, l.st, l.d, ctx->c, ctx->w, u);
 }
 template <int SRC>
-static void launch_se(seir_ctx *ctx, int B, bool grad) {
-    const Dims &d = ctx->d;
-    const dim3 grid(d.ntc, d.nmt, B);
+static void launch_se(seir_ctx *ctx, const LaunchCfg &l, bool grad) {
+    const Dims &d = l.d;
+    const dim3 grid(d.ntc, d.nmt, l.nb);
     if (grad)
-        hipLaunchKernelGGL((k_se<true, SRC>), grid, dim3(256), 0, ctx->stream, d, ctx->c, ctx->w);
+        hipLaunchKernelGGL((k_se<true, SRC>), grid, dim3(256), 0, l.st, d, ctx->c, ctx->w);
     else
-        hipLaunchKernelGGL((k_se<false, SRC>), grid, dim3(256), 0, ctx->stream, d, ctx->c, ctx->w);
+        hipLaunchKernelGGL((k_se<false, SRC>), grid, dim3(256), 0, l.st, d, ctx->c, ctx->w);
 }
-static void launch_finish(seir_ctx *ctx, int B, const double *u, double *logp, double *grad) {
-    const size_t lds = (size_t)ctx->d.Tp * sizeof(double);
+static void launch_finish(seir_ctx *ctx, const LaunchCfg &l, const double *u, double *logp, double *grad) {
+    const size_t lds = (size_t)l.d.Tp * sizeof(double);
     if (grad)
-        hipLaunchKernelGGL(k_finish<true>, dim3(B), dim3(256), lds, ctx->stream, ctx->d, ctx->c, ctx->w, u, logp,
-                           grad);
+        hipLaunchKernelGGL(k_finish<true>, dim3(l.nb), dim3(256), lds, l.st, l.d, ctx->c, ctx->w, u, logp, grad);
     else
-        hipLaunchKernelGGL(k_finish<false>, dim3(B), dim3(256), lds, ctx->stream, ctx->d, ctx->c, ctx->w, u, logp,
-                           grad);
+        hipLaunchKernelGGL(k_finish<false>, dim3(l.nb), dim3(256), lds, l.st, l.d, ctx->c, ctx->w, u, logp, grad);
 }
 
 extern "C" int seir_prepare_events_dev(seir_ctx *ctx, int32_t B, const double *events_dev) {
     int rc = check_batch(ctx, B);
     if (rc) return rc;
     if (!events_dev) return fail(SEIR_ERR_INVALID, "null events pointer");
-    launch_scan<0>(ctx, B, events_dev);
-    launch_colreduce(ctx, B);
-    launch_gemm(ctx, B);
+    launch_scan<0>(ctx, whole(ctx, B), events_dev);
+    launch_colreduce(ctx, whole(ctx, B));
+    launch_gemm(ctx, whole(ctx, B));
     HIP_TRY(hipGetLastError());
     ctx->last_events = events_dev;
     ctx->prepared = true;
@@ -265,9 +308,9 @@ extern "C" int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_
     if (rc) return rc;
     if (!ctx->prepared) return fail(SEIR_ERR_STATE, "seir_prepare_events_dev has not been called");
     if (!u_dev || !logp_dev) return fail(SEIR_ERR_INVALID, "null u/logp pointer");
-    launch_params(ctx, B, u_dev);
-    launch_se<0>(ctx, B, grad_dev != nullptr);
-    launch_finish(ctx, B, u_dev, logp_dev, grad_dev);
+    launch_params(ctx, whole(ctx, B), u_dev);
+    launch_se<0>(ctx, whole(ctx, B), grad_dev != nullptr);
+    launch_finish(ctx, whole(ctx, B), u_dev, logp_dev, grad_dev);
     HIP_TRY(hipGetLastError());
     ctx->last_u = u_dev; ctx->last_logp = logp_dev; ctx->last_grad = grad_dev;
     return 0;
@@ -356,11 +399,11 @@ extern "C" int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t
         return fail(SEIR_ERR_STATE, "last evaluation had no gradient buffer");
     auto once = [&]() {
         switch (which) {
-            case SEIR_K_SCAN: launch_scan<0>(ctx, B, ctx->last_events); break;
-            case SEIR_K_GEMM: launch_gemm(ctx, B); break;
-            case SEIR_K_SE_VALUE: launch_se<0>(ctx, B, false); break;
-            case SEIR_K_SE_GRAD: launch_se<0>(ctx, B, true); break;
-            default: launch_finish(ctx, B, ctx->last_u, ctx->last_logp, ctx->last_grad); break;
+            case SEIR_K_SCAN: launch_scan<0>(ctx, whole(ctx, B), ctx->last_events); break;
+            case SEIR_K_GEMM: launch_gemm(ctx, whole(ctx, B)); break;
+            case SEIR_K_SE_VALUE: launch_se<0>(ctx, whole(ctx, B), false); break;
+            case SEIR_K_SE_GRAD: launch_se<0>(ctx, whole(ctx, B), true); break;
+            default: launch_finish(ctx, whole(ctx, B), ctx->last_u, ctx->last_logp, ctx->last_grad); break;
         }
     };
     if (which < SEIR_K_SCAN || which > SEIR_K_FINISH) return fail(SEIR_ERR_INVALID, "unknown kernel id %d", which);
@@ -376,6 +419,33 @@ extern "C" int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t
     return 0;
 }
 
+__global__ void k_selftest_math(Consts c, int n, const double *x, double *L, double *inv, double *lf) {
+    __shared__ double2 ltab[LOGTAB_N];
+    log_table_to_lds(ltab, c.logtab);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double a, b2;
+        l1me_inv(x[i], a, b2, ltab);
+        L[i] = a; inv[i] = b2;
+        lf[i] = lfact(floor(x[i]), ltab);
+    }
+}
+
+extern "C" int seir_selftest_math(seir_ctx *ctx, int32_t n, const double *x, double *L, double *inv, double *lf) {
+    int rc = check_batch(ctx, 1);
+    if (rc) return rc;
+    if (n < 1 || !x || !L || !inv || !lf) return fail(SEIR_ERR_INVALID, "bad arguments");
+    double *dx = nullptr;
+    HIP_TRY(hipMalloc((void **)&dx, sizeof(double) * 4 * n));
+    HIP_TRY(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest_math, dim3(64), dim3(256), 0, ctx->stream, ctx->c, n, dx, dx + n, dx + 2 * n, dx + 3 * n);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(L, dx + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(inv, dx + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lf, dx + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(dx));
+    return 0;
+}
+
 // ===========================================================================
 // Sampler (see include/seir_hip.h, "Device-resident Metropolis-within-Gibbs")
 // ===========================================================================
@@ -385,8 +455,14 @@ struct seir_sampler {
     Chains ch{};
     int record_events = 1;
     std::vector<void *> allocs;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
+    // chains are independent: they are split into groups that run on their own streams
+    // so that one group's single-workgroup-per-chain kernels overlap another group's wide ones
+    int ngroups = 1;
+    std::vector<hipStream_t> gstream;
+    std::vector<hipGraph_t> graph;
+    std::vector<hipGraphExec_t> gexec;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
     bool use_graph = true;
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
@@ -404,8 +480,8 @@ static int s_alloc(seir_sampler *s, T **p, size_t count) {
 }
 
 static void drop_graph(seir_sampler *s) {
-    if (s->gexec) { (void)hipGraphExecDestroy(s->gexec); s->gexec = nullptr; }
-    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    for (auto &g : s->gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &g : s->graph) if (g) { (void)hipGraphDestroy(g); g = nullptr; }
 }
 
 extern "C" void seir_sampler_destroy(seir_sampler *s) {
@@ -413,6 +489,9 @@ extern "C" void seir_sampler_destroy(seir_sampler *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     drop_graph(s);
+    for (auto st : s->gstream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto e : s->ev_join) if (e) (void)hipEventDestroy(e);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (void *p : s->allocs) (void)hipFree(p);
     Work &w = s->ctx->w;
     for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
@@ -427,6 +506,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     const int B = ds->num_chains;
     if (B < 1 || B > ctx->Bmax) return fail(SEIR_ERR_INVALID, "num_chains=%d outside [1, %d]", B, ctx->Bmax);
     if (ctx->w.K[0]) return fail(SEIR_ERR_STATE, "this context already has a sampler");
+    if (d.Tp > 2 * HB || d.M > 4 * HB)
+        return fail(SEIR_ERR_INVALID, "sampler supports T <= %d and M <= %d", 2 * HB, 4 * HB);
     if (ds->m < 1 || ds->m > MMAX) return fail(SEIR_ERR_INVALID, "m=%d outside [1, %d]", ds->m, MMAX);
     if (ds->dmax < 1 || ds->nmax < 0 || ds->occult_nmax < 0 || ds->num_event_time_updates < 0)
         return fail(SEIR_ERR_INVALID, "bad dmax/nmax/occult_nmax/num_event_time_updates");
@@ -449,6 +530,15 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     c.nrb_d = (d.M + 7) / 8;
     s->record_events = ds->record_events;
     s->use_graph = getenv("SEIR_NO_GRAPH") == nullptr;
+    {
+        const char *e = getenv("SEIR_CHAIN_GROUPS");
+        int g = e ? atoi(e) : (B >= 4 ? 4 : B);
+        if (g < 1) g = 1;
+        if (g > B) g = B;
+        s->ngroups = g;
+        s->gstream.assign(g, nullptr); s->graph.assign(g, nullptr); s->gexec.assign(g, nullptr);
+        s->ev_join.assign(g, nullptr);
+    }
 
     int rc = 0;
     Work &w = ctx->w;
@@ -477,6 +567,14 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         if (e == hipSuccess) e = hipMemcpy(ch.hs, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(SEIR_ERR_DEVICE, "sampler init copy failed: %s", hipGetErrorString(e));
     }
+    if (!rc) {
+        hipError_t e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+        for (int g = 0; g < s->ngroups && e == hipSuccess; ++g) {
+            e = hipStreamCreateWithFlags(&s->gstream[g], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join[g], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) rc = fail(SEIR_ERR_DEVICE, "sampler stream setup failed: %s", hipGetErrorString(e));
+    }
     if (rc) { seir_sampler_destroy(s); return rc; }
     *out = s;
     return 0;
@@ -492,11 +590,11 @@ static void enqueue_refresh(seir_sampler *s) {
     seir_ctx *ctx = s->ctx;
     const Dims &d = ctx->d;
     const int B = s->cfg.B;
-    launch_scan<1>(ctx, B, nullptr);
-    launch_colreduce(ctx, B);
-    launch_gemm(ctx, B);
+    launch_scan<1>(ctx, whole(ctx, B), nullptr);
+    launch_colreduce(ctx, whole(ctx, B));
+    launch_gemm(ctx, whole(ctx, B));
     hipLaunchKernelGGL(k_chain_tables, dim3(B), dim3(256), 0, ctx->stream, d, ctx->c, ctx->w, s->ch);
-    launch_se<1>(ctx, B, false);
+    launch_se<1>(ctx, whole(ctx, B), false);
     hipLaunchKernelGGL(k_chain_refresh, dim3(B), dim3(256), (size_t)d.Tp * sizeof(double), ctx->stream, d, ctx->c,
                        ctx->w, s->ch);
 }
@@ -654,24 +752,57 @@ extern "C" int seir_sampler_reset_trace(seir_sampler *s) {
     return 0;
 }
 
-static void enqueue_sweep(seir_sampler *s) {
-    seir_ctx *ctx = s->ctx;
-    const Dims &d = ctx->d;
-    const SamplerCfg &c = s->cfg;
-    const int B = c.B;
-    hipStream_t st = ctx->stream;
-    const size_t lds = (size_t)d.Tp * sizeof(double);
-    // [part 0] HMC on u | events: L+1 gradient evaluations
-    launch_se<1>(ctx, B, true);
-    hipLaunchKernelGGL(k_hmc_step<0>, dim3(B), dim3(256), lds, st, d, ctx->c, ctx->w, c, s->ch);
-    for (int l = 1; l < c.L; ++l) {
-        launch_se<1>(ctx, B, true);
-        hipLaunchKernelGGL(k_hmc_step<1>, dim3(B), dim3(256), lds, st, d, ctx->c, ctx->w, c, s->ch);
+template <int HT, int HM>
+static void launch_hmc_t(seir_ctx *ctx, const LaunchCfg &l, const SamplerCfg &c, const Chains &ch, int stage) {
+    const size_t lds = (size_t)l.d.Mp * sizeof(double);
+    const dim3 g(l.nb), blk(HB);
+    if (stage == 0)
+        hipLaunchKernelGGL((k_hmc_step<0, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch);
+    else if (stage == 1)
+        hipLaunchKernelGGL((k_hmc_step<1, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch);
+    else
+        hipLaunchKernelGGL((k_hmc_step<2, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch);
+}
+static void launch_hmc(seir_ctx *ctx, const LaunchCfg &l, const SamplerCfg &c, const Chains &ch, int stage) {
+    const int ht = (l.d.Tp + HB - 1) / HB, hm = (l.d.M + HB - 1) / HB;    // sampler_create caps T<=1024, M<=2048
+    if (ht <= 1) {
+        if (hm <= 1) launch_hmc_t<1, 1>(ctx, l, c, ch, stage);
+        else if (hm <= 2) launch_hmc_t<1, 2>(ctx, l, c, ch, stage);
+        else launch_hmc_t<1, 4>(ctx, l, c, ch, stage);
+    } else {
+        if (hm <= 1) launch_hmc_t<2, 1>(ctx, l, c, ch, stage);
+        else if (hm <= 2) launch_hmc_t<2, 2>(ctx, l, c, ch, stage);
+        else launch_hmc_t<2, 4>(ctx, l, c, ch, stage);
     }
-    launch_se<1>(ctx, B, true);
-    hipLaunchKernelGGL(k_hmc_step<2>, dim3(B), dim3(256), lds, st, d, ctx->c, ctx->w, c, s->ch);
+}
+
+// chains [b0, b0+nb) of group g
+static void group_range(const seir_sampler *s, int g, int &b0, int &nb) {
+    const int B = s->cfg.B, G = s->ngroups;
+    b0 = (int)((long long)B * g / G);
+    nb = (int)((long long)B * (g + 1) / G) - b0;
+}
+
+static void enqueue_sweep(seir_sampler *s, int g) {
+    seir_ctx *ctx = s->ctx;
+    const SamplerCfg &c = s->cfg;
+    int b0, nb;
+    group_range(s, g, b0, nb);
+    LaunchCfg l{ctx->d, s->gstream[g], nb};
+    l.d.b0 = b0;
+    const Dims &d = l.d;
+    hipStream_t st = l.st;
+    // [part 0] HMC on u | events: L+1 gradient evaluations
+    launch_se<1>(ctx, l, true);
+    launch_hmc(ctx, l, c, s->ch, 0);
+    for (int i = 1; i < c.L; ++i) {
+        launch_se<1>(ctx, l, true);
+        launch_hmc(ctx, l, c, s->ch, 1);
+    }
+    launch_se<1>(ctx, l, true);
+    launch_hmc(ctx, l, c, s->ch, 2);
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I])
-    const dim3 gm(c.nrb_d, B);
+    const dim3 gm(c.nrb_d, nb);
     int have_prev = 0, pbuf = 0;
     for (int scan = 0; scan < c.n_scans; ++scan)
         for (int slot = 0; slot < 4; ++slot) {
@@ -685,8 +816,8 @@ static void enqueue_sweep(seir_sampler *s) {
         const MoveSpec none{-1, 0, 0, 0};
         hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
     }
-    if (s->record_events) hipLaunchKernelGGL(k_record, dim3(32, B), dim3(256), 0, st, d, ctx->w, c, s->ch);
-    hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, st, s->ch, B);
+    if (s->record_events) hipLaunchKernelGGL(k_record, dim3(32, nb), dim3(256), 0, st, d, ctx->w, c, s->ch);
+    hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);
 }
 
 extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
@@ -694,16 +825,28 @@ extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
     if (rc) return rc;
     if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
     if (n < 0) return fail(SEIR_ERR_INVALID, "num_sweeps must be >= 0");
-    hipStream_t st = s->ctx->stream;
-    if (s->use_graph && !s->gexec) {
-        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        enqueue_sweep(s);
-        HIP_TRY(hipStreamEndCapture(st, &s->graph));
-        HIP_TRY(hipGraphInstantiate(&s->gexec, s->graph, nullptr, nullptr, 0));
+    hipStream_t main_st = s->ctx->stream;
+    // fork: every group stream starts after what is already queued on the context stream
+    HIP_TRY(hipEventRecord(s->ev_fork, main_st));
+    for (int g = 0; g < s->ngroups; ++g) {
+        hipStream_t st = s->gstream[g];
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_fork, 0));
+        if (s->use_graph && !s->gexec[g]) {
+            HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            enqueue_sweep(s, g);
+            HIP_TRY(hipStreamEndCapture(st, &s->graph[g]));
+            HIP_TRY(hipGraphInstantiate(&s->gexec[g], s->graph[g], nullptr, nullptr, 0));
+        }
     }
-    for (int i = 0; i < n; ++i) {
-        if (s->use_graph) HIP_TRY(hipGraphLaunch(s->gexec, st));
-        else enqueue_sweep(s);
+    for (int i = 0; i < n; ++i)
+        for (int g = 0; g < s->ngroups; ++g) {
+            if (s->use_graph) HIP_TRY(hipGraphLaunch(s->gexec[g], s->gstream[g]));
+            else enqueue_sweep(s, g);
+        }
+    // join: the context stream continues after every group has finished
+    for (int g = 0; g < s->ngroups; ++g) {
+        HIP_TRY(hipEventRecord(s->ev_join[g], s->gstream[g]));
+        HIP_TRY(hipStreamWaitEvent(main_st, s->ev_join[g], 0));
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -742,9 +885,9 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
     if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
     if (!mean_ms || iters < 1) return fail(SEIR_ERR_INVALID, "bad iters/mean_ms");
     seir_ctx *ctx = s->ctx;
-    launch_se<1>(ctx, s->cfg.B, true);
+    launch_se<1>(ctx, whole(ctx, s->cfg.B), true);
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < iters; ++i) launch_se<1>(ctx, s->cfg.B, true);
+    for (int i = 0; i < iters; ++i) launch_se<1>(ctx, whole(ctx, s->cfg.B), true);
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;

@@ -145,3 +145,10 @@ class SeirModel:
         ms_ = ctypes.c_float()
         _lib.check(self._lib.seir_time_kernel(self._ctx, self.KERNELS[which], B, iters, ctypes.byref(ms_)))
         return float(ms_.value)
+
+    def selftest_math(self, x):
+        """Device values of log(1-exp(-x)), 1/expm1(x), log Gamma(floor(x)+1) (csrc/device_math.h)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        L, inv, lf = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+        _lib.check(self._lib.seir_selftest_math(self._ctx, x.size, _dptr(x), _dptr(L), _dptr(inv), _dptr(lf)))
+        return L, inv, lf

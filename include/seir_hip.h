@@ -121,6 +121,11 @@ enum { SEIR_K_SCAN = 0, SEIR_K_GEMM = 1, SEIR_K_SE_VALUE = 2, SEIR_K_SE_GRAD = 3
        SEIR_K_FINISH = 4 };
 int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t iters, float *mean_ms);
 
+/* Self-test hook for the device math the kernels share (csrc/device_math.h):
+ * for each x[i] > 0 returns L[i] = log(1-exp(-x)), inv[i] = 1/expm1(x) and
+ * lfact[i] = log Gamma(floor(x)+1) as the kernels evaluate them.  Host pointers. */
+int seir_selftest_math(seir_ctx *ctx, int32_t n, const double *x, double *L, double *inv, double *lfact);
+
 
 /* ------------------------------------------------------------------------
  * Device-resident Metropolis-within-Gibbs sampler.

@@ -89,3 +89,25 @@ def test_workload_shapes():
         assert st.min() >= 0 and ev.min() >= 0
         assert np.all(ev[..., 0] <= st[..., 0]) and np.all(ev[..., 1] <= st[..., 1])
         assert np.all(ev[..., 2] <= st[..., 2])
+
+
+def test_series_constants():
+    """The small-rate series in csrc/device_math.h: literals equal the exact Taylor
+    coefficients and the truncated series meet 3e-16 on (0, 1/8] (mpmath reference)."""
+    import mpmath as mp
+    text = open(os.path.join(ROOT, "covid19uk_amd", "csrc", "device_math.h")).read()
+    lits = sorted(set(float(x) for x in re.findall(r"\d\.\d{10,}e-\d+", text)))
+    exact = sorted([1 / 24, 1 / 2880, 1 / 181440, 1 / 9676800, 1 / 12, 1 / 720, 1 / 30240, 1 / 1209600,
+                    1 / 12, 1 / 360, 1 / 1260, 1 / 1680, 1 / 3, 1 / 6, 1 / 7, 2.3190468138462996e-17])
+    for v in lits:
+        assert min(abs(v - e) / e for e in exact) < 1e-15, v
+    m = re.search(r"L1ME_SERIES_MAX = ([0-9.]+);", text)
+    rmax = float(m.group(1))
+    mp.mp.dps = 40
+    for r in list(np.logspace(-12, np.log10(rmax), 60)) + [rmax]:
+        r2 = r * r
+        L = np.log(r) + r * (-0.5 + r * (1 / 24 - r2 * (1 / 2880 - r2 * (1 / 181440 - r2 / 9676800))))
+        inv = 1 / r - 0.5 + r * (1 / 12 - r2 * (1 / 720 - r2 * (1 / 30240 - r2 / 1209600)))
+        Lt = mp.log(1 - mp.e ** (-mp.mpf(r)))
+        It = 1 / (mp.e ** mp.mpf(r) - 1)
+        assert abs((mp.mpf(L) - Lt) / Lt) < 3e-16 and abs((mp.mpf(inv) - It) / It) < 3e-16

@@ -173,3 +173,23 @@ def test_argument_errors(Model):
             model.log_prob(case["u"][:-1], case["events"])
         with pytest.raises(_lib.SeirError):
             model.log_prob(np.stack([case["u"]] * 2), np.stack([case["events"]] * 2))   # B > max_chains
+
+
+def test_device_math_against_mpmath(Model):
+    """The table log / Newton reciprocal / series behind every cell: 1e-15 relative against
+    50-digit references over the rates and counts the model produces."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    case = H.build_case("micro_2x3", 13)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-9), np.log(5.0), 4000)),
+                        [1e-9, 0.125, 0.1250001, 1.0, 0.28, 63.5, 64.0, 65.2, 1e3, 1.2e6]])
+    with Model(case["cov"], case["init"]) as model:
+        L, inv, lf = model.selftest_math(x)
+    for i in range(0, len(x), 7):
+        xi = mp.mpf(float(x[i]))
+        Lt, it = mp.log(1 - mp.e ** (-xi)), 1 / (mp.e ** xi - 1)
+        assert abs((mp.mpf(float(L[i])) - Lt) / Lt) < 2e-15 or abs(mp.mpf(float(L[i])) - Lt) < 2e-16, (x[i], L[i])
+        assert abs((mp.mpf(float(inv[i])) - it) / it) < 2e-15, (x[i], inv[i])
+        lt = mp.loggamma(mp.floor(xi) + 1)
+        assert abs(mp.mpf(float(lf[i])) - lt) <= 2e-15 * max(1, abs(lt)), (x[i], lf[i])
