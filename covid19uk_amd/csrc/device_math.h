@@ -114,15 +114,50 @@ __device__ __forceinline__ double log1mexp(double r, const double2 *tab) {
 // same without a table (cold paths)
 __device__ __forceinline__ double log1mexp(double r) { return log(-expm1(-r)); }
 
-__device__ __forceinline__ double softplus(double x) {
-    return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x));
+// Out-of-line libm for the once-per-launch scalar work: inlining every exp/log/log1p copy makes
+// the single-workgroup kernels several thousand instructions of straight-line code that is
+// fetched cold on every launch.
+__device__ __attribute__((noinline)) double cold_exp(double x) { return exp(x); }
+__device__ __attribute__((noinline)) double cold_log(double x) { return log(x); }
+__device__ __attribute__((noinline)) double softplus(double x) {
+    return x > 0.0 ? x + log1p(cold_exp(-x)) : log1p(cold_exp(x));
 }
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding
+// global load/store (s_waitcnt vmcnt(0)), which serialises prefetched loads behind each reduction.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
+}
+
+// DPP data movement of a double (two v_mov_b32_dpp): lanes that are masked off or whose
+// source falls outside the 16-lane row receive 0.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes with the GCN DPP reduction (row_shr 1,2,3,4,8, row_bcast 15,31):
+// register-to-register moves (~8 cycles) instead of ds_bpermute round trips through the LDS
+// crossbar (~130 cycles each).  The result is uniform (read from lane 63).
+template <>
+__device__ __forceinline__ double wave_sum<double>(double v0) {
+    double v = v0 + dpp_mov0<0x111, 0xf, 0xf>(v0);
+    v += dpp_mov0<0x112, 0xf, 0xf>(v0);
+    v += dpp_mov0<0x113, 0xf, 0xf>(v0);
+    v += dpp_mov0<0x114, 0xf, 0xe>(v);
+    v += dpp_mov0<0x118, 0xf, 0xc>(v);
+    v += dpp_mov0<0x142, 0xa, 0xf>(v);
+    v += dpp_mov0<0x143, 0xc, 0xf>(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double wave_min(double v) {

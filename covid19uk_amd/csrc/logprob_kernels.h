@@ -273,7 +273,7 @@ __device__ inline void param_tables(const Dims &d, const Consts &c, const Work &
         double lp = d.prior_const;
         lp += -0.5 * a0 * a0 / 100.0;                                 // alpha_0 ~ N(0,10)
         lp += -0.5 * beta * beta;                                     // beta_area ~ N(0,1)
-        lp += 2.0 * log(psi) - 10.0 * psi;                            // psi ~ Gamma(3,10)
+        lp += 2.0 * cold_log(psi) - 10.0 * psi;                       // psi ~ Gamma(3,10)
         lp += -0.5 * q_at / (0.005 * 0.005);                          // alpha_t ~ N(0, 0.005)
         lp += -sig * sig / 0.02;                                      // sigma_space ~ HalfNormal(0.1)
         lp += -0.5 * quad;                                            // CAR, precision form
@@ -281,8 +281,8 @@ __device__ inline void param_tables(const Dims &d, const Consts &c, const Work &
         double *sc = w.scal + (size_t)b * NSCAL;
         sc[SC_PSI] = psi; sc[SC_SIG] = sig; sc[SC_BETA] = beta; sc[SC_G0] = g0; sc[SC_G1] = g1;
         sc[SC_A0] = a0;
-        const double ls0 = -softplus(-u[0]), ls1 = -softplus(-u[1]);
-        sc[SC_S0] = exp(ls0); sc[SC_S1] = exp(ls1);
+        const double ls0 = u[0] - (psi - eps), ls1 = u[1] - (sig - eps);   // log sigmoid(u) = u - softplus(u)
+        sc[SC_S0] = cold_exp(ls0); sc[SC_S1] = cold_exp(ls1);
         sc[SC_PRIOR] = lp;
         sc[SC_JAC] = ls0 + ls1;                     // inverse_log_det_jacobian, inference.py:555-557
     }

@@ -132,6 +132,19 @@ constexpr int HB = 512;             // threads (8 waves: leaves 256 VGPRs per la
 constexpr int HWV = HB / WAVE;      // waves
 // HT / HM (template parameters): days / rows per thread, ceil(Tp/HB) in {1,2}, ceil(M/HB) in {1,2,4}
 constexpr int NRED = 8;
+#ifdef SEIR_STAMPS
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) ((unsigned long long *)(hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+// standard normal for component i of the momentum (Box-Muller; components 2j, 2j+1 share a Philox call)
+__device__ __attribute__((noinline)) double momentum_normal(RngKey key, int i) {
+    double u1, u2;
+    rng_uniform2(key, RS_MOMENTUM, (uint32_t)(i >> 1), u1, u2);
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+    return (i & 1) ? rad * sin(ang) : rad * cos(ang);
+}
 
 // sum NV values over the block; results replicated in every thread.  sh: [HWV][NRED]
 template <int NV>
@@ -139,12 +152,12 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[NV], double *sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
-    __syncthreads();
+    lds_barrier();
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) sh[wave * NRED + k] = v[k];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         double a = 0.0;
@@ -158,9 +171,9 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[NV], double *sh) {
 __device__ __forceinline__ double block_excl_scan_hb(double v, double *sh, double &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double inc = wave_incl_scan(v, lane);
-    __syncthreads();
+    lds_barrier();
     if (lane == 63) sh[wave] = inc;
-    __syncthreads();
+    lds_barrier();
     double base = 0.0, tot = 0.0;
 #pragma unroll
     for (int j = 0; j < HWV; ++j) { const double x = sh[j]; tot += x; if (j < wave) base += x; }
@@ -172,9 +185,9 @@ __device__ __forceinline__ double block_excl_scan_hb(double v, double *sh, doubl
 __device__ __forceinline__ double block_incl_suffix_hb(double v, double *sh, double &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double inc = wave_incl_suffix_scan(v, lane);
-    __syncthreads();
+    lds_barrier();
     if (lane == 0) sh[wave] = inc;
-    __syncthreads();
+    lds_barrier();
     double tail = 0.0, tot = 0.0;
 #pragma unroll
     for (int j = 0; j < HWV; ++j) { const double x = sh[j]; tot += x; if (j > wave) tail += x; }
@@ -198,6 +211,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     double *sc = w.scal + (size_t)b * NSCAL;
     const int oT = 6 - 1, oM = 6 + T - 1;              // alpha_t[t-1] at oT + t ; spatial[m] at oM + m
 
+    STAMP(0);
     // ---------------- phase 0: all loads --------------------------------------
     if (tid < LOGTAB_N) ltab[tid] = c.logtab[tid];
     const double eps = hs[HS_EPS];
@@ -217,17 +231,25 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             dir[k] = w.Dir[(size_t)b * d.Tp + t];
             rate[k] = w.rir[(size_t)b * d.Tp + t];
             wdt[k] = c.wd[t];
+            if (t >= 1 && t < T) { qa[k] = q[oT + t]; pa[k] = STAGE == 0 ? 0.0 : p[oT + t]; va[k] = var[oT + t]; }
             const double *kp = w.Kpart + (size_t)b * d.nmt * d.Tp + t;
             double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-            for (int ty0 = 0; ty0 < d.nmt; ty0 += 16) {
+            if (d.nmt <= 16) {                           // one batch of loads, no loop-carried waits
                 double v[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ty0 + j < d.nmt ? kp[(size_t)(ty0 + j) * d.Tp] : 0.0;
+                for (int j = 0; j < 16; ++j) v[j] = j < d.nmt ? kp[(size_t)j * d.Tp] : 0.0;
 #pragma unroll
                 for (int j = 0; j < 16; j += 4) { c0 += v[j]; c1 += v[j + 1]; c2 += v[j + 2]; c3 += v[j + 3]; }
+            } else {
+                for (int ty0 = 0; ty0 < d.nmt; ty0 += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = ty0 + j < d.nmt ? kp[(size_t)(ty0 + j) * d.Tp] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 16; j += 4) { c0 += v[j]; c1 += v[j + 1]; c2 += v[j + 2]; c3 += v[j + 3]; }
+                }
             }
             col[k] = (c0 + c1) + (c2 + c3);
-            if (t >= 1 && t < T) { qa[k] = q[oT + t]; pa[k] = STAGE == 0 ? 0.0 : p[oT + t]; va[k] = var[oT + t]; }
         }
     }
 #pragma unroll
@@ -235,20 +257,20 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         const int m = tid + k * HB;
         Rm[k] = lam[k] = qs[k] = qm[k] = pm[k] = inN[k] = 0.0; vm[k] = 1.0;
         if (m < M) {
-            const double *rp = w.Rpart + (size_t)b * d.ntc * d.Mp + m;
-            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-            for (int tx0 = 0; tx0 < d.ntc; tx0 += 16) {
-                double v[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = tx0 + j < d.ntc ? rp[(size_t)(tx0 + j) * d.Mp] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 16; j += 4) { r0 += v[j]; r1 += v[j + 1]; r2 += v[j + 2]; r3 += v[j + 3]; }
-            }
-            Rm[k] = (r0 + r1) + (r2 + r3);
             lam[k] = c.la[m];
             inN[k] = c.invN[m];
             qs[k] = w.Qs[(size_t)b * d.Mp + m];
             qm[k] = q[oM + m]; pm[k] = STAGE == 0 ? 0.0 : p[oM + m]; vm[k] = var[oM + m];
+            const double *rp = w.Rpart + (size_t)b * d.ntc * d.Mp + m;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+            {                                            // ntc = Tp/64 <= 16 (T <= 1024)
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = j < d.ntc ? rp[(size_t)j * d.Mp] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) { r0 += v[j]; r1 += v[j + 1]; r2 += v[j + 2]; r3 += v[j + 3]; }
+            }
+            Rm[k] = (r0 + r1) + (r2 + r3);
         }
     }
     double q6[6], p6[6], v6[6];
@@ -256,7 +278,8 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
 #pragma unroll
         for (int i = 0; i < 6; ++i) { q6[i] = q[i]; p6[i] = STAGE == 0 ? 0.0 : p[i]; v6[i] = var[i]; }
     }
-    __syncthreads();                                   // ltab
+    lds_barrier();                                     // ltab
+    STAMP(1);
 
     // ---------------- phase 1: gradient at the current position ---------------
     double rv[6] = {lpart, 0.0, 0.0, 0.0, 0.0, ppart};  // lik, gg0, gg1, gsig, gbeta, gpsi
@@ -278,7 +301,9 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         rv[3] += qm[k] * Rm[k];
         rv[4] += lam[k] * Rm[k];
     }
+    STAMP(2);
     block_sum_vec<6>(rv, red);
+    STAMP(3);
     const double lp_theta = rv[0] + prior + jac;
     // d/d alpha_t[t-1] = sum_{t' >= t} col[t']: suffix scan, chunks from the back
     double ga[HT], gtot = 0.0;
@@ -308,16 +333,12 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     g6[4] = rv[2] - g1 / 1.0e4;
     g6[5] = gtot - a0 / 100.0;
 
+    STAMP(4);
     // ---------------- phase 2: leapfrog on the owned entries -------------------
     double kin = 0.0;                                   // kinetic energy contribution (STAGE 0: start, 2: end)
     if (STAGE == 0) {
         const RngKey key = rng_key(s, ch, b);
-        auto draw = [&](int i) {                       // standard normal of component i (pairs share a Philox call)
-            double u1, u2;
-            rng_uniform2(key, RS_MOMENTUM, (uint32_t)(i >> 1), u1, u2);
-            const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
-            return (i & 1) ? rad * sin(ang) : rad * cos(ang);
-        };
+        auto draw = [&](int i) { return momentum_normal(key, i); };
 #pragma unroll
         for (int k = 0; k < HT; ++k) {
             const int t = tid + k * HB;
@@ -390,7 +411,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             rng_uniform2(key, RS_HMC_ACCEPT, 0u, u1, u2);
             const double lp0 = hs[HS_LP0];
             const double log_ratio = (lp_theta - lp0) - (kin - hs[HS_K0]);
-            const int acc = log(u1) < log_ratio ? 1 : 0;          // NaN compares false -> reject
+            const int acc = cold_log(u1) < log_ratio ? 1 : 0;     // NaN compares false -> reject
             s_accept = acc;
             hs[HS_ACC] = (double)acc;
             hs[HS_LOGACC] = log_ratio;
@@ -404,16 +425,16 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
                 tr[2] = eps;
             }
             if (s.adapt_step) {                       // dual averaging (Hoffman & Gelman alg. 5, TFP defaults)
-                const double a = isfinite(log_ratio) ? fmin(1.0, exp(log_ratio)) : 0.0;
+                const double a = isfinite(log_ratio) ? fmin(1.0, cold_exp(log_ratio)) : 0.0;
                 const double prev_step = hs[HS_DA_STEP];
                 const double n = prev_step + 1.0;
                 const double err = hs[HS_DA_ERR] + s.target_accept - a;
                 const double log_step = hs[HS_DA_MU] - err * sqrt(n) / ((n + 10.0) * 0.05);
-                const double eta = pow(n, -0.75);
+                const double eta = cold_exp(-0.75 * cold_log(n));
                 const double log_avg = eta * log_step + (1.0 - eta) * hs[HS_DA_LOGAVG];
                 hs[HS_DA_ERR] = err; hs[HS_DA_STEP] = n; hs[HS_DA_LOGAVG] = log_avg;
                 if (prev_step <= (double)s.n_adapt)
-                    hs[HS_EPS] = prev_step < (double)s.n_adapt ? exp(log_step) : exp(log_avg);
+                    hs[HS_EPS] = cold_exp(prev_step < (double)s.n_adapt ? log_step : log_avg);
             }
         }
         __syncthreads();
@@ -450,6 +471,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             if (tid == 0) hs[HS_RV_N] = n1;
         }
     }
+    STAMP(5);
     // write back position / momentum
 #pragma unroll
     for (int k = 0; k < HT; ++k) {
@@ -469,7 +491,8 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         bc[2] = q6[2]; bc[3] = q6[3]; bc[4] = q6[4]; bc[5] = q6[5];
         bc[6] = q6[0]; bc[7] = q6[1];
     }
-    __syncthreads();                                   // bc, lds_sp
+    lds_barrier();                                     // bc, lds_sp (LDS only: do not drain the stores)
+    STAMP(6);
 
     // ---------------- phase 3: tables and priors at the new position -----------
     const double npsi = bc[0], nsig = bc[1], nbeta = bc[2], ng0 = bc[3], ng1 = bc[4], na0 = bc[5];
@@ -515,23 +538,27 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             pr[1] += qm[k] * acc;
         }
     }
+    STAMP(7);
     block_sum_vec<2>(pr, red);
+    STAMP(8);
     if (tid == 0) {
         // model_spec.py:140-198; the parameter-free normalisers are folded into d.prior_const
         double lp = d.prior_const;
         lp += -0.5 * na0 * na0 / 100.0 - 0.5 * nbeta * nbeta;
-        lp += 2.0 * log(npsi) - 10.0 * npsi;
+        lp += 2.0 * cold_log(npsi) - 10.0 * npsi;
         lp += -0.5 * pr[0] / (0.005 * 0.005);
         lp += -nsig * nsig / 0.02;
         lp += -0.5 * pr[1];
         lp += -0.5 * (ng0 * ng0 + ng1 * ng1) / 1.0e4;
         sc[SC_PSI] = npsi; sc[SC_SIG] = nsig; sc[SC_BETA] = nbeta; sc[SC_G0] = ng0; sc[SC_G1] = ng1;
         sc[SC_A0] = na0;
-        const double ls0 = -softplus(-bc[6]), ls1 = -softplus(-bc[7]);
-        sc[SC_S0] = exp(ls0); sc[SC_S1] = exp(ls1);
+        // log sigmoid(u) = u - softplus(u)
+        const double ls0 = bc[6] - (npsi - 2.220446049250313e-16), ls1 = bc[7] - (nsig - 2.220446049250313e-16);
+        sc[SC_S0] = cold_exp(ls0); sc[SC_S1] = cold_exp(ls1);
         sc[SC_PRIOR] = lp;
         sc[SC_JAC] = ls0 + ls1;
     }
+    STAMP(9);
     if (STAGE == 2) {
         // constrained draw -> trace (param_bijector.inverse(draws[0]), inference.py:375)
         const unsigned slot = ch.sweep[b] - ch.slot0[0];

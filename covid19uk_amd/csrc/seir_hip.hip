@@ -896,3 +896,11 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
     *mean_ms = ms / iters;
     return 0;
 }
+
+#ifdef SEIR_STAMPS
+extern "C" int seir_sampler_debug_hs(seir_sampler *s, double *out) {
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    HIP_TRY(hipMemcpy(out, s->ch.hs, sizeof(double) * s->cfg.B * NHS, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif

@@ -1,0 +1,25 @@
+import ctypes, os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from covid19uk_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libseirhip_stamps.so")
+from covid19uk_amd import synth
+from covid19uk_amd.sampler import ChainSampler
+from covid19uk_amd.seir import SeirModel
+os.environ["SEIR_NO_GRAPH"] = "1"
+cfg = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=0)
+cov = synth.make_covariates("uk380")
+events, init, truth = synth.simulate_epidemic(cov)
+u0 = synth.unconstrain(synth.pack_params(truth, cov.M, cov.T))
+B = 8
+u = synth.jitter_params(u0, B, scale=0.002, seed=7, T=cov.T)
+ev = np.stack([events] * B)
+lib = _lib.load()
+lib.seir_sampler_debug_hs.argtypes = [ctypes.c_void_p, _lib.c_double_p]
+with SeirModel(cov, init, max_chains=B) as model:
+    with ChainSampler(model, cfg, B, seed=1, trace_capacity=10, record_events=False) as s:
+        s.set_state(u, ev); s.set_kernel(step_size=1.2e-5)
+        s.reset_trace(); s.run(3); model.sync()
+        hs = np.empty((B, 32))
+        lib.seir_sampler_debug_hs(s._s, hs.ctypes.data_as(_lib.c_double_p))
+        st = hs[0, 16:26].view(np.uint64).astype(np.int64)
+        print("stamps (10ns ticks) deltas:", np.diff(st) * 10, "ns ; total", (st[-1] - st[0]) * 10, "ns")
