@@ -1,0 +1,315 @@
+"""Minimal HDF5 reader/writer over the C library (ctypes -> libhdf5).
+
+The reference reads its input with xarray/netCDF4 (NetCDF4 files ARE HDF5
+files; covid19uk/inference/inference.py:481-485) and writes `posterior.hd5`
+with h5py through gemlib's `Posterior` (inference.py:352-358,588-592).  Neither
+package exists in this image, but libhdf5 does (/opt/conda/lib/libhdf5.so
+1.10.6), so this module binds the dozen C calls the path needs: create / open
+files, nested groups, N-d datasets of float64 / int32 / int8 / fixed strings,
+hyperslab writes along the first axis (Posterior.write_samples'
+`first_dim_offset`), whole-dataset reads with type conversion (which also
+decodes chunked / deflated NetCDF4 variables) and string attributes.
+
+If no libhdf5 can be loaded, `available()` is False and the CLI falls back to
+`.npz` files (inference.py of this package); nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import ctypes.util
+import os
+
+import numpy as np
+
+_CANDIDATES = [
+    os.environ.get("SEIR_LIBHDF5", ""),
+    "/opt/conda/lib/libhdf5.so",
+    "/opt/conda/lib/libhdf5.so.103",
+    ctypes.util.find_library("hdf5") or "",
+    ctypes.util.find_library("hdf5_serial") or "",
+    "libhdf5.so", "libhdf5_serial.so",
+]
+
+hid_t = ctypes.c_int64
+hsize_t = ctypes.c_uint64
+_lib = None
+_ids = {}
+
+H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC = 0, 1, 2
+H5P_DEFAULT, H5S_ALL, H5S_SELECT_SET = 0, 0, 0
+H5T_INTEGER, H5T_FLOAT, H5T_STRING = 0, 1, 3
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    err = None
+    for cand in _CANDIDATES:
+        if not cand:
+            continue
+        try:
+            lib = ctypes.CDLL(cand)
+            lib.H5open()
+            break
+        except (OSError, AttributeError) as e:      # pragma: no cover - depends on the host
+            err = e
+            lib = None
+    if lib is None:
+        raise OSError(f"libhdf5 not found ({err}); set SEIR_LIBHDF5=/path/to/libhdf5.so")
+
+    def fn(name, res, *args):
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, list(args)
+        return f
+    c_char_p, c_void_p, c_int, c_uint, c_size_t = (ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_uint, ctypes.c_size_t)
+    hp = ctypes.POINTER(hsize_t)
+    fn("H5Fcreate", hid_t, c_char_p, c_uint, hid_t, hid_t)
+    fn("H5Fopen", hid_t, c_char_p, c_uint, hid_t)
+    fn("H5Fclose", c_int, hid_t)
+    fn("H5Fflush", c_int, hid_t, c_int)
+    fn("H5Gopen2", hid_t, hid_t, c_char_p, hid_t)
+    fn("H5Gclose", c_int, hid_t)
+    fn("H5Screate_simple", hid_t, c_int, hp, hp)
+    fn("H5Sclose", c_int, hid_t)
+    fn("H5Sselect_hyperslab", c_int, hid_t, c_int, hp, hp, hp, hp)
+    fn("H5Sget_simple_extent_ndims", c_int, hid_t)
+    fn("H5Sget_simple_extent_dims", c_int, hid_t, hp, hp)
+    fn("H5Dcreate2", hid_t, hid_t, c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t)
+    fn("H5Dopen2", hid_t, hid_t, c_char_p, hid_t)
+    fn("H5Dwrite", c_int, hid_t, hid_t, hid_t, hid_t, hid_t, c_void_p)
+    fn("H5Dread", c_int, hid_t, hid_t, hid_t, hid_t, hid_t, c_void_p)
+    fn("H5Dclose", c_int, hid_t)
+    fn("H5Dget_space", hid_t, hid_t)
+    fn("H5Dget_type", hid_t, hid_t)
+    fn("H5Tget_class", c_int, hid_t)
+    fn("H5Tget_size", c_size_t, hid_t)
+    fn("H5Tcopy", hid_t, hid_t)
+    fn("H5Tset_size", c_int, hid_t, c_size_t)
+    fn("H5Tclose", c_int, hid_t)
+    fn("H5Tis_variable_str", c_int, hid_t)
+    fn("H5Pcreate", hid_t, hid_t)
+    fn("H5Pset_chunk", c_int, hid_t, c_int, hp)
+    fn("H5Pset_create_intermediate_group", c_int, hid_t, c_uint)
+    fn("H5Pclose", c_int, hid_t)
+    fn("H5Lexists", c_int, hid_t, c_char_p, hid_t)
+    fn("H5Aexists_by_name", c_int, hid_t, c_char_p, c_char_p, hid_t)
+    fn("H5Aopen_by_name", hid_t, hid_t, c_char_p, c_char_p, hid_t, hid_t)
+    fn("H5Aget_type", hid_t, hid_t)
+    fn("H5Aread", c_int, hid_t, hid_t, c_void_p)
+    fn("H5Aclose", c_int, hid_t)
+    fn("H5Eset_auto2", c_int, hid_t, c_void_p, c_void_p)
+    lib.H5Eset_auto2(0, None, None)                  # errors are reported through return codes
+    for name in ("H5T_NATIVE_DOUBLE_g", "H5T_NATIVE_INT32_g", "H5T_NATIVE_INT8_g", "H5T_NATIVE_INT64_g",
+                 "H5T_C_S1_g", "H5P_CLS_DATASET_CREATE_ID_g", "H5P_CLS_LINK_CREATE_ID_g"):
+        _ids[name] = hid_t.in_dll(lib, name).value
+    _lib = lib
+    return lib
+
+
+def available() -> bool:
+    try:
+        _load()
+        return True
+    except OSError:
+        return False
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise OSError(f"HDF5: {what} failed")
+    return rc
+
+
+_NATIVE = {np.dtype("float64"): "H5T_NATIVE_DOUBLE_g", np.dtype("int32"): "H5T_NATIVE_INT32_g",
+           np.dtype("int8"): "H5T_NATIVE_INT8_g", np.dtype("int64"): "H5T_NATIVE_INT64_g"}
+
+
+def _dims(shape):
+    return (hsize_t * len(shape))(*[int(x) for x in shape])
+
+
+class File:
+    """`File(path, "w" | "r" | "a")`; dataset names are '/'-separated paths."""
+
+    def __init__(self, path, mode="r"):
+        lib = _load()
+        self._lib = lib
+        p = os.fsencode(path)
+        if mode == "w":
+            self._f = lib.H5Fcreate(p, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+        elif mode == "a":
+            self._f = lib.H5Fopen(p, H5F_ACC_RDWR, H5P_DEFAULT) if os.path.exists(path) else \
+                lib.H5Fcreate(p, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+        else:
+            self._f = lib.H5Fopen(p, H5F_ACC_RDONLY, H5P_DEFAULT)
+        _check(self._f, f"open {path!r} ({mode})")
+        self._dsets = {}
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_f", -1) >= 0:
+            for d in self._dsets.values():
+                self._lib.H5Dclose(d)
+            self._dsets = {}
+            self._lib.H5Fclose(self._f)
+            self._f = -1
+
+    def flush(self):
+        self._lib.H5Fflush(self._f, 1)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- structure ------------------------------------------------------------
+    def exists(self, name) -> bool:
+        parts = [p for p in name.split("/") if p]
+        path = ""
+        for part in parts:
+            path += "/" + part
+            if self._lib.H5Lexists(self._f, path.encode(), H5P_DEFAULT) <= 0:
+                return False
+        return True
+
+    def _open(self, name):
+        if name not in self._dsets:
+            d = self._lib.H5Dopen2(self._f, name.encode(), H5P_DEFAULT)
+            _check(d, f"open dataset {name!r}")
+            self._dsets[name] = d
+        return self._dsets[name]
+
+    def create_dataset(self, name, shape, dtype, chunk_rows=None):
+        """N-d dataset (intermediate groups are created).  dtype: float64, int32, int8, int64
+        or 'S<n>' fixed-length strings.  chunk_rows: chunk extent of axis 0 (None = contiguous)."""
+        lib = self._lib
+        dt = np.dtype(dtype)
+        own_type = False
+        if dt.kind == "S":
+            tid = lib.H5Tcopy(_ids["H5T_C_S1_g"])
+            lib.H5Tset_size(tid, dt.itemsize)
+            own_type = True
+        else:
+            tid = _ids[_NATIVE[dt]]
+        shape = tuple(int(x) for x in shape)
+        space = lib.H5Screate_simple(len(shape), _dims(shape) if shape else None, None)
+        lcpl = lib.H5Pcreate(_ids["H5P_CLS_LINK_CREATE_ID_g"])
+        lib.H5Pset_create_intermediate_group(lcpl, 1)
+        dcpl = H5P_DEFAULT
+        if chunk_rows and shape and shape[0] > 0:
+            dcpl = lib.H5Pcreate(_ids["H5P_CLS_DATASET_CREATE_ID_g"])
+            lib.H5Pset_chunk(dcpl, len(shape), _dims((min(int(chunk_rows), shape[0]),) + shape[1:]))
+        d = lib.H5Dcreate2(self._f, name.encode(), tid, space, lcpl, dcpl, H5P_DEFAULT)
+        lib.H5Sclose(space)
+        lib.H5Pclose(lcpl)
+        if dcpl != H5P_DEFAULT:
+            lib.H5Pclose(dcpl)
+        if own_type:
+            lib.H5Tclose(tid)
+        _check(d, f"create dataset {name!r}")
+        self._dsets[name] = d
+
+    def write(self, name, array, offset=0):
+        """ds[offset:offset+n] = array (the rest of the axes must match)."""
+        lib = self._lib
+        d = self._open(name)
+        a = np.ascontiguousarray(array)
+        ftype = lib.H5Dget_type(d)
+        cls = lib.H5Tget_class(ftype)
+        if cls == H5T_STRING:
+            mtype, own = lib.H5Tcopy(ftype), True
+            a = np.ascontiguousarray(a.astype(f"S{lib.H5Tget_size(ftype)}"))
+        else:
+            if a.dtype == np.bool_:
+                a = a.astype(np.int8)
+            if a.dtype not in _NATIVE:
+                a = a.astype(np.float64)
+            mtype, own = _ids[_NATIVE[a.dtype]], False
+        lib.H5Tclose(ftype)
+        fspace = lib.H5Dget_space(d)
+        nd = lib.H5Sget_simple_extent_ndims(fspace)
+        if nd == 0:
+            rc = lib.H5Dwrite(d, mtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(ctypes.c_void_p))
+        else:
+            fd = (hsize_t * nd)()
+            lib.H5Sget_simple_extent_dims(fspace, fd, None)
+            shape = tuple(a.shape) if a.ndim == nd else (1,) + tuple(a.shape)
+            if tuple(fd)[1:] != shape[1:] or offset + shape[0] > fd[0]:
+                lib.H5Sclose(fspace)
+                raise ValueError(f"write to {name!r}: block {shape} at {offset} does not fit {tuple(fd)}")
+            start = _dims((offset,) + (0,) * (nd - 1))
+            lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, None, _dims(shape), None)
+            mspace = lib.H5Screate_simple(nd, _dims(shape), None)
+            rc = lib.H5Dwrite(d, mtype, mspace, fspace, H5P_DEFAULT, a.ctypes.data_as(ctypes.c_void_p))
+            lib.H5Sclose(mspace)
+        lib.H5Sclose(fspace)
+        if own:
+            lib.H5Tclose(mtype)
+        _check(rc, f"write {name!r}")
+
+    def shape(self, name):
+        lib = self._lib
+        d = self._open(name)
+        sp = lib.H5Dget_space(d)
+        nd = lib.H5Sget_simple_extent_ndims(sp)
+        fd = (hsize_t * max(nd, 1))()
+        if nd > 0:
+            lib.H5Sget_simple_extent_dims(sp, fd, None)
+        lib.H5Sclose(sp)
+        return tuple(int(x) for x in fd[:nd])
+
+    def read(self, name):
+        """Whole dataset as float64 / int64 / fixed bytes (by HDF5 type class)."""
+        lib = self._lib
+        d = self._open(name)
+        shape = self.shape(name)
+        ftype = lib.H5Dget_type(d)
+        cls = lib.H5Tget_class(ftype)
+        if cls == H5T_STRING:
+            if lib.H5Tis_variable_str(ftype) > 0:
+                n = int(np.prod(shape)) if shape else 1
+                ptrs = (ctypes.c_char_p * n)()
+                rc = lib.H5Dread(d, ftype, H5S_ALL, H5S_ALL, H5P_DEFAULT, ptrs)
+                out = np.array([p or b"" for p in ptrs]).reshape(shape)
+            else:
+                out = np.empty(shape, dtype=f"S{lib.H5Tget_size(ftype)}")
+                rc = lib.H5Dread(d, ftype, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.ctypes.data_as(ctypes.c_void_p))
+        else:
+            out = np.empty(shape, dtype=np.float64 if cls == H5T_FLOAT else np.int64)
+            rc = lib.H5Dread(d, _ids[_NATIVE[out.dtype]], H5S_ALL, H5S_ALL, H5P_DEFAULT,
+                             out.ctypes.data_as(ctypes.c_void_p))
+        lib.H5Tclose(ftype)
+        _check(rc, f"read {name!r}")
+        return out
+
+    def read_str_attr(self, obj, attr):
+        """String attribute `attr` of object `obj`, or None."""
+        lib = self._lib
+        if lib.H5Aexists_by_name(self._f, obj.encode(), attr.encode(), H5P_DEFAULT) <= 0:
+            return None
+        a = lib.H5Aopen_by_name(self._f, obj.encode(), attr.encode(), H5P_DEFAULT, H5P_DEFAULT)
+        if a < 0:
+            return None
+        t = lib.H5Aget_type(a)
+        out = None
+        if lib.H5Tget_class(t) == H5T_STRING:
+            if lib.H5Tis_variable_str(t) > 0:
+                p = ctypes.c_char_p()
+                if lib.H5Aread(a, t, ctypes.byref(p)) >= 0 and p.value is not None:
+                    out = p.value.decode(errors="replace")
+            else:
+                buf = ctypes.create_string_buffer(lib.H5Tget_size(t) + 1)
+                if lib.H5Aread(a, t, buf) >= 0:
+                    out = buf.value.decode(errors="replace")
+        lib.H5Tclose(t)
+        lib.H5Aclose(a)
+        return out

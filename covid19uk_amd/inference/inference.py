@@ -1,0 +1,305 @@
+"""MCMC driver for the COVID-19 UK spatial SEIR model on MI355X.
+
+Host-side mirror of the reference's `covid19uk/inference/inference.py`: the same
+CLI (`python -m covid19uk_amd.inference.inference -c config.yaml -o posterior.hd5
+data.nc`; `python -m covid19uk.inference.inference` forwards here), the same
+`config["Mcmc"]` keys, the same windowed warm-up schedule and the same
+`posterior.hd5` layout.  Everything numerical -- the joint log-probability, HMC,
+the event-time and occult Metropolis-Hastings kernels -- runs in libseirhip's HIP
+kernels through `covid19uk_amd.sampler.ChainSampler`; this file only sequences
+windows and moves draws from the device burst buffer to disk.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+from .. import hdf5io
+from .. import model_spec
+from ..sampler import MOVE_KEYS, ChainSampler
+from ..seir import SeirModel
+from .mcmc_kernel_factory import event_kernel_config, hmc_kernel_kwargs_default
+
+DTYPE = model_spec.DTYPE
+
+
+# ---------------------------------------------------------------------------
+# inference data (the reference's NetCDF4 `constant_data` / `observations` groups)
+# ---------------------------------------------------------------------------
+def read_inference_data(path):
+    """(Covariates, cases [M,T], dates [T] of str) from the file `assemble_data` writes
+    (covid19uk/data/assemble.py:8-16; variables of model_spec.py:88-105).  `.npz` files with
+    the same variable names are accepted too."""
+    if str(path).endswith(".npz"):
+        d = np.load(path, allow_pickle=False)
+        cov = model_spec.Covariates(C=d["C"], W=d["W"], N=d["N"], adjacency=d["adjacency"],
+                                    weekday=d["weekday"], area=d["area"])
+        dates = [str(x) for x in d["time"]] if "time" in d.files else [str(i) for i in range(cov.T)]
+        return cov, np.asarray(d["cases"], DTYPE), dates
+    with hdf5io.File(path, "r") as f:
+        g = {k: f.read(f"/constant_data/{k}") for k in ("C", "W", "N", "adjacency", "weekday", "area")}
+        cases = np.asarray(f.read("/observations/cases"), DTYPE)
+        dates = None
+        if f.exists("/observations/time"):
+            t = f.read("/observations/time")
+            if t.dtype.kind == "S":
+                dates = [x.decode() for x in t]
+            else:
+                units = f.read_str_attr("/observations/time", "units") or ""
+                if units.startswith("days since "):
+                    t0 = np.datetime64(units[len("days since "):].split()[0])
+                    dates = [str(t0 + np.timedelta64(int(x), "D")) for x in t]
+                else:
+                    dates = [str(int(x)) for x in t]
+    cov = model_spec.Covariates(**{k: np.asarray(v, DTYPE) for k, v in g.items()})
+    if cases.shape == (cov.T, cov.M) and cov.T != cov.M:
+        cases = cases.T
+    if dates is None:
+        dates = [str(i) for i in range(cases.shape[1])]
+    return cov, cases, dates
+
+
+def write_inference_data(path, cov: model_spec.Covariates, cases, dates=None):
+    """Write an input file with the layout `read_inference_data` expects (tests, synthetic runs)."""
+    cases = np.asarray(cases, DTYPE)
+    dates = [str(i) for i in range(cases.shape[1])] if dates is None else list(dates)
+    if str(path).endswith(".npz"):
+        np.savez(path, C=cov.C, W=cov.W, N=cov.N, adjacency=cov.adjacency, weekday=cov.weekday, area=cov.area,
+                 cases=cases, time=np.array(dates))
+        return
+    with hdf5io.File(path, "w") as f:
+        for k in ("C", "W", "N", "adjacency", "weekday", "area"):
+            a = np.asarray(getattr(cov, k), DTYPE)
+            f.create_dataset(f"/constant_data/{k}", a.shape, np.float64)
+            f.write(f"/constant_data/{k}", a)
+        f.create_dataset("/observations/cases", cases.shape, np.float64)
+        f.write("/observations/cases", cases)
+        n = max(len(s) for s in dates)
+        f.create_dataset("/observations/time", (len(dates),), f"S{n}")
+        f.write("/observations/time", np.array(dates, dtype=f"S{n}"))
+
+
+# ---------------------------------------------------------------------------
+# posterior.hd5 (gemlib `Posterior`: samples/<key>, results/<nested/keys>)
+# ---------------------------------------------------------------------------
+class Posterior:
+    """HDF5 sink with the dataset layout of inference.py:285-300 / :245-282 / :588-592.
+    `is_accepted` is stored as int8 0/1 (h5py stores numpy bool as an int8 enum)."""
+
+    def __init__(self, filename, M, T, mmax, num_samples, burst=100):
+        self.filename = filename
+        self.use_h5 = not str(filename).endswith(".npz") and hdf5io.available()
+        self.shapes = {
+            "samples/psi": (), "samples/sigma_space": (), "samples/beta_area": (), "samples/gamma0": (),
+            "samples/gamma1": (), "samples/alpha_0": (), "samples/alpha_t": (T - 1,),
+            "samples/spatial_effect": (M,), "samples/seir": (M, T, 3),
+            "results/hmc/is_accepted": (), "results/hmc/target_log_prob": (), "results/hmc/step_size": (),
+        }
+        self.dtypes = {"results/hmc/is_accepted": np.int8}
+        for key in MOVE_KEYS:
+            self.shapes[f"results/{key}/is_accepted"] = ()
+            self.shapes[f"results/{key}/target_log_prob"] = ()
+            self.shapes[f"results/{key}/proposed_delta"] = (4, mmax)
+            self.dtypes[f"results/{key}/is_accepted"] = np.int8
+        self.num_samples = int(num_samples)
+        if self.use_h5:
+            self._file = hdf5io.File(filename, "w")
+            for name, shp in self.shapes.items():
+                self._file.create_dataset("/" + name, (self.num_samples,) + shp, self.dtypes.get(name, np.float64),
+                                          chunk_rows=burst if name == "samples/seir" else None)
+        else:
+            self._file = None
+            self._mem = {name: np.zeros((self.num_samples,) + shp, self.dtypes.get(name, np.float64))
+                         for name, shp in self.shapes.items()}
+            self._extra = {}
+
+    def write(self, name, value, first_dim_offset):
+        if self.use_h5:
+            self._file.write("/" + name, value, offset=first_dim_offset)
+        else:
+            v = np.asarray(value)
+            self._mem[name][first_dim_offset:first_dim_offset + v.shape[0]] = v
+
+    def write_samples(self, samples: dict, first_dim_offset):
+        for k, v in samples.items():
+            self.write(f"samples/{k}", v, first_dim_offset)
+
+    def write_results(self, results: dict, first_dim_offset):
+        for k, v in results.items():
+            for kk, vv in v.items():
+                self.write(f"results/{k}/{kk}", vv, first_dim_offset)
+
+    def create_dataset(self, name, data):
+        data = np.asarray(data)
+        if self.use_h5:
+            self._file.create_dataset("/" + name, data.shape, data.dtype if data.dtype.kind == "S" else np.float64)
+            self._file.write("/" + name, data)
+        else:
+            self._extra[name] = data
+
+    def __getitem__(self, name):
+        if self.use_h5:
+            self._file.flush()
+            return self._file.read("/" + name)
+        return self._mem[name]
+
+    def close(self):
+        if self.use_h5:
+            self._file.close()
+        else:
+            out = {k.replace("/", "__"): v for k, v in {**self._mem, **self._extra}.items()}
+            np.savez(self.filename, **out)
+
+
+def get_weighted_running_variance(u_draws):
+    """inference.py:36-47: mean/variance of the second half of a window's (unconstrained)
+    draws, with pseudo-count n/2.  u_draws [n,B,P] -> (count [B], mean [B,P], var [B,P])."""
+    n = u_draws.shape[0]
+    half = u_draws[-(n // 2):]
+    mean, var = half.mean(axis=0), half.var(axis=0)
+    return np.full(u_draws.shape[1], n / 2.0), mean, np.maximum(var, 1e-300)
+
+
+def unconstrain_theta(theta):
+    u = np.array(theta, dtype=DTYPE, copy=True)
+    y = u[..., :2] - np.finfo(DTYPE).eps
+    u[..., :2] = y + np.log(-np.expm1(-y))
+    return u
+
+
+def draws_to_dict(theta, events, chain):
+    """inference.py:285-300 for one chain: theta [n,B,P] constrained, events [n,B,M,T,3]."""
+    M, T = events.shape[2], events.shape[3]
+    th = theta[:, chain]
+    return {
+        "psi": th[:, 0], "sigma_space": th[:, 1], "beta_area": th[:, 2], "gamma0": th[:, 3],
+        "gamma1": th[:, 4], "alpha_0": th[:, 5], "alpha_t": th[:, 6:6 + T - 1],
+        "spatial_effect": th[:, 6 + T - 1:6 + T - 1 + M],
+        "seir": events[:, chain].astype(DTYPE),
+    }
+
+
+def trace_to_dict(tr, chain):
+    """trace_results_fn (inference.py:245-282) for one chain."""
+    out = {"hmc": {k: v[:, chain] for k, v in tr.hmc.items()}}
+    for key in MOVE_KEYS:
+        out[key] = {k: v[:, chain] for k, v in tr.moves[key].items()}
+    return out
+
+
+def run_mcmc(sampler: ChainSampler, config, posteriors, log=sys.stderr):
+    """The windowed schedule of inference.py:303-470: fast 200, slow 25*2^k (k<6), fast 50,
+    then num_bursts x num_burst_samples with the kernel fixed.  Every draw -- warm-up
+    included -- is written, as in the reference."""
+    first_window_size, last_window_size, slow_window_size, num_slow_windows = 200, 50, 25, 6
+    dual_averaging_kwargs = {"target_accept_prob": 0.75}
+    offset = 0
+
+    def flush(tr):
+        nonlocal offset
+        n = tr.theta.shape[0]
+        for c, post in enumerate(posteriors):
+            post.write_samples(draws_to_dict(tr.theta, tr.events, c), first_dim_offset=offset)
+            post.write_results(trace_to_dict(tr, c), first_dim_offset=offset)
+        offset += n
+
+    def window(n, adapt_mass, running_variance=None):
+        sampler.set_adaptation(adapt_step_size=True, adapt_mass=adapt_mass, num_adaptation_steps=n,
+                               running_variance=running_variance, **dual_averaging_kwargs)
+        tr = sampler.sample(n)
+        flush(tr)
+        return tr, get_weighted_running_variance(unconstrain_theta(tr.theta))
+
+    print(f"Fast window {first_window_size}", file=log, flush=True)
+    sampler.set_kernel(step_size=hmc_kernel_kwargs_default()["step_size"])
+    tr, running_variance = window(first_window_size, False)
+    for k in range(num_slow_windows):
+        n = slow_window_size * 2 ** k
+        print(f"Slow window {n}", file=log, flush=True)
+        tr, running_variance = window(n, True, running_variance)
+    print(f"Fast window {last_window_size}", file=log, flush=True)
+    tr, _ = window(last_window_size, False)
+
+    print("Sampling...", file=log, flush=True)
+    step_size = tr.hmc["step_size"][-(last_window_size // 2):].mean(axis=0)      # inference.py:439-441
+    sampler.set_adaptation(adapt_step_size=False)
+    sampler.set_kernel(step_size=step_size, variance=sampler.get_kernel()[1])
+    nb, ns = int(config["num_bursts"]), int(config["num_burst_samples"])
+    t0 = time.perf_counter()
+    for i in range(nb):
+        flush(sampler.sample(ns))
+        print(f"  burst {i + 1}/{nb}", file=log, flush=True)
+    dt = time.perf_counter() - t0
+    if nb * ns:
+        print(f"Sampling: {nb * ns * sampler.B / dt:.1f} posterior samples/s "
+              f"({sampler.B} chain(s), device->host->disk included)", file=log, flush=True)
+    return offset
+
+
+def warmup_size():
+    return 200 + 25 * (2 ** 6 - 1) + 50          # inference.py:312-322
+
+
+def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=0):
+    """Constructs and runs the MCMC (covid19uk/inference/inference.py:473-608)."""
+    cov, cases, dates = read_inference_data(data_file)
+    rng = np.random.default_rng(seed)
+    B = int(num_chains)
+    inits, evs = zip(*[model_spec.initial_conditions(cases, cov.N, rng) for _ in range(1)])
+    initial_state, events = inits[0], evs[0]
+    M, T = events.shape[0], events.shape[1]
+    P = model_spec.num_params(M, T)
+    cfg = event_kernel_config(config)
+    num_samples = warmup_size() + int(config["num_burst_samples"]) * int(config["num_bursts"])
+    cap = max(800, int(config["num_burst_samples"]))
+
+    model = SeirModel(cov, initial_state, max_chains=B, device=device)
+    sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),
+                           num_leapfrog_steps=hmc_kernel_kwargs_default()["num_leapfrog_steps"],
+                           trace_capacity=cap, record_events=True)
+    u0 = np.zeros((B, P))                                   # inference.py:563-573
+    sampler.set_state(u0, np.stack([events] * B))
+    print("Initial logpi:", sampler.log_prob(), flush=True)
+
+    def out_name(c):
+        if B == 1:
+            return output_file
+        root, ext = os.path.splitext(output_file)
+        return f"{root}_chain{c}{ext}"
+    posteriors = [Posterior(out_name(c), M, T, cfg["m"], num_samples, burst=int(config["num_burst_samples"]))
+                  for c in range(B)]
+    run_mcmc(sampler, config, posteriors)
+    for post in posteriors:
+        post.create_dataset("initial_state", initial_state)
+        n = max(len(s) for s in dates)
+        post.create_dataset("time", np.array(dates, dtype=f"S{n}"))
+        print(f"Acceptance theta: {post['results/hmc/is_accepted'].mean()}")
+        for key, label in zip(MOVE_KEYS, ("move S->E", "move E->I", "occult S->E", "occult E->I")):
+            print(f"Acceptance {label}: {post[f'results/{key}/is_accepted'].mean()}")
+        post.close()
+    sampler.close()
+    model.close()
+
+
+def main(argv=None):
+    from argparse import ArgumentParser
+
+    import yaml
+    parser = ArgumentParser(description="Run MCMC inference algorithm")
+    parser.add_argument("-c", "--config", type=str, help="Config file", required=True)
+    parser.add_argument("-o", "--output", type=str, help="Output file", required=True)
+    parser.add_argument("data_file", type=str, help="Data NetCDF file")
+    parser.add_argument("--seed", type=int, default=0, help="RNG seed (the reference is unseeded)")
+    parser.add_argument("--chains", type=int, default=1, help="independent chains on this GPU")
+    parser.add_argument("--device", type=int, default=0)
+    args = parser.parse_args(argv)
+    with open(args.config, "r") as f:
+        config = yaml.load(f, Loader=yaml.FullLoader)
+    mcmc(args.data_file, args.output, config["Mcmc"], seed=args.seed, num_chains=args.chains, device=args.device)
+
+
+if __name__ == "__main__":
+    main()

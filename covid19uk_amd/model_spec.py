@@ -103,3 +103,65 @@ def compute_state(initial_state, events):
     cs = np.cumsum(inc, axis=-2)
     cs = np.concatenate([np.zeros_like(cs[..., :1, :]), cs[..., :-1, :]], axis=-2)
     return np.asarray(initial_state, DTYPE)[..., None, :] + cs
+
+
+# ---------------------------------------------------------------------------
+# Initialisation of the censored events (host side, once per run)
+# ---------------------------------------------------------------------------
+def distribute_geom(events, rate, rng, delta_t=1.0):
+    """Spread `events` [M,T] back in time with geometric waiting times of
+    per-step probability 1-exp(-rate*delta_t) (covid19uk/util.py:120-145).
+    Returns [M, L, T]; slice l holds the events whose lag is l (lag 0 is empty,
+    as in the reference, whose loop counter starts at 1)."""
+    ev = np.asarray(events, dtype=np.int64)
+    prob = 1.0 - np.exp(-rate * delta_t)
+    out = [np.zeros_like(ev)]
+    remaining = ev.copy()
+    while remaining.sum() > 0:
+        hit = rng.binomial(remaining, prob)
+        out.append(hit)
+        remaining = remaining - hit
+    return np.stack(out, axis=1).astype(DTYPE)
+
+
+def reduce_diagonals(m):
+    """[M, L, T] -> [M, L+T-1]: element (l, t) lands on day t - l + L - 1 (util.py:148-159)."""
+    M, L, T = m.shape
+    out = np.zeros((M, L + T - 1), dtype=m.dtype)
+    for lag in range(L):
+        out[:, L - 1 - lag:L - 1 - lag + T] += m[:, lag, :]
+    return out
+
+
+def impute_previous_cases(events, rate, rng, delta_t=1.0):
+    """util.py:162-182: back-distributed events with the leading all-zero days trimmed,
+    and the number of days the series grew by."""
+    distn = distribute_geom(events, rate, rng, delta_t)
+    prev = reduce_diagonals(distn)
+    total = prev.sum(axis=-2)
+    num_zero_days = total.shape[-1] - int(np.count_nonzero(np.cumsum(total)))
+    return prev[..., num_zero_days:], distn.shape[-2] - num_zero_days
+
+
+def impute_censored_events(cases, rng):
+    """model_spec.py:108-126 of the reference: S->E and E->I events imputed from the observed
+    I->R series with the reference's rates 0.25 and 0.5.  cases [M,T] -> events [M,T',3]."""
+    cases = np.asarray(cases, dtype=DTYPE)
+    ei_events, lag_ei = impute_previous_cases(cases, 0.25, rng)
+    se_events, lag_se = impute_previous_cases(ei_events, 0.5, rng)
+    ir_events = np.pad(cases, ((0, 0), (lag_ei + lag_se - 2, 0)))
+    ei_events = np.pad(ei_events, ((0, 0), (lag_se - 1, 0)))
+    return np.stack([se_events, ei_events, ir_events], axis=-1)
+
+
+def initial_conditions(cases, N, rng, extra_weeks=3):
+    """inference.py:487-513: repeat the last week `extra_weeks` times, impute the censored
+    events, and return (initial_state [M,4], events [M,T,3]) for the observed window."""
+    cases = np.asarray(cases, dtype=DTYPE)
+    extra = np.tile(cases[:, -7:], (1, extra_weeks))
+    padded = np.concatenate([cases, extra], axis=-1)
+    events = impute_censored_events(padded, rng)
+    init = np.concatenate([np.asarray(N, DTYPE).reshape(-1, 1), np.zeros_like(events[:, 0, :])], axis=-1)
+    state = compute_state(init, events)
+    start = state.shape[1] - padded.shape[1]
+    return state[:, start, :].copy(), events[:, start:-extra.shape[1], :].copy()

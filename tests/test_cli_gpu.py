@@ -1,0 +1,55 @@
+"""GPU end-to-end: the drop-in CLI surface (`python -m covid19uk.inference.inference`) on the
+11-LAD example size: data file in, posterior.hd5 out with the reference's layout, sane
+acceptance rates and a posterior that recovers the generating parameters."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+from covid19uk_amd import hdf5io, synth
+from covid19uk_amd.inference import inference as inf
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_end_to_end_ni11(tmp_path):
+    cov = synth.make_covariates("ni11")
+    events, init, truth = synth.simulate_epidemic(cov)
+    data = str(tmp_path / "inferencedata.nc")
+    dates = [str(np.datetime64("2021-01-01") + np.timedelta64(i, "D")) for i in range(cov.T)]
+    inf.write_inference_data(data, cov, events[..., 2], dates)
+    cfg = {"Mcmc": dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5,
+                        num_bursts=3, num_burst_samples=100, thin=1, num_adaptation_iterations=1000)}
+    cfg_path = str(tmp_path / "config.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = str(tmp_path / "posterior.hd5")
+    env = dict(os.environ, PYTHONPATH=H.ROOT)
+    r = subprocess.run([sys.executable, "-m", "covid19uk.inference.inference", "-c", cfg_path, "-o", out,
+                        "--seed", "4", data], cwd=H.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Initial logpi" in r.stdout and "Acceptance theta" in r.stdout
+    n = 1825 + 300
+    with hdf5io.File(out, "r") as f:
+        assert f.shape("/samples/seir") == (n, cov.M, cov.T, 3)
+        assert f.shape("/samples/alpha_t") == (n, cov.T - 1)
+        assert f.shape("/results/move/E->I/proposed_delta") == (n, 4, 2)
+        assert f.shape("/initial_state") == (cov.M, 4)
+        assert [x.decode() for x in f.read("/time")] == dates
+        lp = f.read("/results/hmc/target_log_prob")
+        assert np.isfinite(lp).all()
+        acc = f.read("/results/hmc/is_accepted")[1825:].mean()
+        assert 0.4 < acc <= 1.0, acc
+        for key in ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I"):
+            a = f.read(f"/results/{key}/is_accepted").mean()
+            assert 0.01 < a < 0.99, (key, a)
+        seir = f.read("/samples/seir")
+        assert np.array_equal(seir[-1][..., 2], events[..., 2])      # removals are data
+        g0 = f.read("/samples/gamma0")[1825:]
+        assert abs(g0.mean() - truth["gamma0"]) < 0.35, g0.mean()     # I->R rate is well identified
+        psi = f.read("/samples/psi")
+        assert (psi > 0).all()

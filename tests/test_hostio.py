@@ -1,0 +1,90 @@
+"""CPU-only: HDF5 layer, inference-data round trip, Posterior layout, host init."""
+import numpy as np
+import pytest
+
+from covid19uk_amd import hdf5io, model_spec as ms, synth
+from covid19uk_amd.inference import inference as inf
+from covid19uk_amd.inference.mcmc_kernel_factory import event_kernel_config
+
+pytestmark = pytest.mark.skipif(not hdf5io.available(), reason="libhdf5 not loadable")
+
+
+def test_hdf5_roundtrip(tmp_path):
+    p = str(tmp_path / "a.h5")
+    with hdf5io.File(p, "w") as f:
+        f.create_dataset("/g/h/x", (6, 2, 3), np.float64, chunk_rows=2)
+        f.create_dataset("/g/flags", (6,), np.int8)
+        f.create_dataset("/names", (2,), "S4")
+        for i in range(3):
+            f.write("/g/h/x", np.full((2, 2, 3), i + 0.5), offset=2 * i)
+        f.write("/g/flags", np.array([1, 0, 1, 1, 0, 0], dtype=bool))
+        f.write("/names", np.array([b"ab", b"cdef"]))
+        with pytest.raises(ValueError):
+            f.write("/g/h/x", np.zeros((2, 2, 3)), offset=5)
+    with hdf5io.File(p, "r") as f:
+        assert f.exists("/g/h/x") and not f.exists("/g/nope")
+        x = f.read("/g/h/x")
+        assert x.shape == (6, 2, 3) and np.array_equal(x[:, 0, 0], [0.5, 0.5, 1.5, 1.5, 2.5, 2.5])
+        assert np.array_equal(f.read("/g/flags"), [1, 0, 1, 1, 0, 0])
+        assert list(f.read("/names")) == [b"ab", b"cdef"]
+
+
+def test_inference_data_roundtrip(tmp_path):
+    cov = synth.make_covariates("ni11")
+    ev, _, _ = synth.simulate_epidemic(cov)
+    dates = [str(np.datetime64("2021-01-01") + np.timedelta64(i, "D")) for i in range(cov.T)]
+    for name in ("d.nc", "d.npz"):
+        p = str(tmp_path / name)
+        inf.write_inference_data(p, cov, ev[..., 2], dates)
+        cov2, cases2, dates2 = inf.read_inference_data(p)
+        assert np.array_equal(cov2.C, cov.C) and np.array_equal(cov2.N, cov.N)
+        assert np.array_equal(cases2, ev[..., 2]) and dates2 == dates
+
+
+def test_posterior_layout_matches_reference_schema(tmp_path):
+    # inference.py:285-300 (samples), :245-282 (results), :588-592 (extras); thin.py:11-14 reads these
+    p = str(tmp_path / "posterior.hd5")
+    M, T, m, n = 3, 5, 2, 7
+    post = inf.Posterior(p, M, T, m, n)
+    theta = np.arange(n * 1 * (6 + T - 1 + M), dtype=float).reshape(n, 1, -1)
+    events = np.ones((n, 1, M, T, 3), dtype=np.int32)
+    post.write_samples(inf.draws_to_dict(theta[:4], events[:4], 0), 0)
+    post.write_samples(inf.draws_to_dict(theta[4:], events[4:], 0), 4)
+    post.create_dataset("initial_state", np.zeros((M, 4)))
+    post.close()
+    with hdf5io.File(p, "r") as f:
+        for k, shp in {"psi": (n,), "alpha_t": (n, T - 1), "spatial_effect": (n, M), "seir": (n, M, T, 3)}.items():
+            assert f.shape(f"/samples/{k}") == shp
+        assert np.array_equal(f.read("/samples/gamma0"), theta[:, 0, 3])
+        assert f.shape("/results/move/S->E/proposed_delta") == (n, 4, m)
+        assert f.shape("/results/occult/E->I/is_accepted") == (n,)
+        assert f.shape("/results/hmc/step_size") == (n,)
+        assert f.shape("/initial_state") == (M, 4)
+
+
+def test_initial_conditions_follow_reference_recipe():
+    cov = synth.make_covariates("ni11")
+    ev, _, _ = synth.simulate_epidemic(cov)
+    cases = ev[..., 2]
+    init, events = ms.initial_conditions(cases, cov.N, np.random.default_rng(3))
+    assert events.shape == (cov.M, cov.T, 3) and init.shape == (cov.M, 4)
+    assert np.array_equal(events[..., 2], cases)           # observed removals untouched
+    st = ms.compute_state(init, events)
+    assert st.min() >= 0 and np.allclose(st.sum(-1), cov.N[:, None])
+    assert np.all(events[..., 1] <= st[..., 1]) and np.all(events[..., 2] <= st[..., 2])
+    # reduce_diagonals places (lag l, day t) on day t - l
+    m = np.zeros((1, 3, 4))
+    m[0, 1, 2] = 5
+    m[0, 2, 3] = 7
+    assert np.array_equal(ms.reduce_diagonals(m)[0], [0, 0, 0, 12, 0, 0])
+
+
+def test_window_bookkeeping():
+    assert inf.warmup_size() == 1825                       # inference.py:312-322
+    u = np.random.default_rng(0).normal(size=(10, 2, 4))
+    cnt, mean, var = inf.get_weighted_running_variance(u)
+    assert np.allclose(cnt, 5.0) and np.allclose(mean, u[5:].mean(0)) and np.allclose(var, u[5:].var(0))
+    th = np.array([[0.3, 2.0, -1.0]])
+    assert np.allclose(np.log1p(np.exp(inf.unconstrain_theta(th)[0, :2])) + np.finfo(float).eps, th[0, :2])
+    with pytest.raises(KeyError):
+        event_kernel_config({"dmax": 1})
