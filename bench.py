@@ -54,7 +54,8 @@ def cpu_baseline(cov, init, events, u0, n_sweeps, seed):
     the reference does) on the host cores, C restatement of the density with OpenMP."""
     from oracle import c_binding, mcmc_oracle as mo, seir_oracle as so
     k = so.make_constants(cov.C, cov.N, cov.W, cov.weekday, cov.area, cov.adjacency, init)
-    cores = len(os.sched_getaffinity(0))
+    # the box's CPU share for one GPU is 16 cores; more OpenMP threads than that only add overhead
+    cores = min(len(os.sched_getaffinity(0)), 16)
     c_binding.set_threads(cores)
     lp = lambda u, ev: c_binding.evaluate(k, u, ev, 1)                      # noqa: E731
     lpg = lambda u, ev: c_binding.evaluate(k, u, ev, 1, want_grad=True)     # noqa: E731
@@ -94,22 +95,24 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist.barrier()
+    from covid19uk_amd import distributed as D
     from covid19uk_amd import synth
     from covid19uk_amd.sampler import ChainSampler
     from covid19uk_amd.seir import SeirModel
 
     B = a.chains_per_gpu
+    first_chain, _ = D.shard_chains(world * B, world, rank)
     cov = synth.make_covariates(a.workload, a.seed)
     events, init, truth = synth.simulate_epidemic(cov, a.seed)
     u_true = synth.unconstrain(synth.pack_params(truth, cov.M, cov.T))
     # every chain of the job gets its own start point (global chain id = rank*B + b)
     u_all = synth.jitter_params(u_true, world * B, scale=0.002, seed=7, T=cov.T)
-    u0 = u_all[rank * B:(rank + 1) * B].copy()
+    u0 = u_all[first_chain:first_chain + B].copy()
     ev0 = np.stack([events] * B)
     K, W = a.steps, a.warmup
 
     model = SeirModel(cov, init, max_chains=B, device=local)
-    sampler = ChainSampler(model, MCMC_CONFIG, B, seed=a.seed, first_chain_id=rank * B,
+    sampler = ChainSampler(model, MCMC_CONFIG, B, seed=a.seed, first_chain_id=first_chain,
                            trace_capacity=max(K, 1), record_events=True)
     sampler.set_state(u0, ev0)
     sampler.set_kernel(step_size=2e-5)
@@ -121,12 +124,7 @@ def main():
         sampler.run(a.adapt_sweeps)
         model.sync()
     eps, _ = sampler.get_kernel()
-    log_eps = torch.tensor(np.log(eps), device=f"cuda:{local}")
-    if world > 1:
-        gathered = [torch.empty_like(log_eps) for _ in range(world)]
-        dist.all_gather(gathered, log_eps)
-        log_eps = torch.cat(gathered)
-    pooled = float(torch.exp(log_eps.mean()).cpu())
+    pooled = D.pool_step_sizes(eps, device=local)       # all_gather over RCCL when world > 1
     sampler.set_adaptation(adapt_step_size=False)
     sampler.set_kernel(step_size=pooled)
 
@@ -146,11 +144,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    elapsed = float(t_all.cpu())
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=local)
 
     # draws leave the device between bursts: D2H of the whole burst buffer (PCIe-inclusive rate)
     t1 = time.perf_counter()

@@ -109,6 +109,13 @@ def load():
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'). "
                 "This package has no CPU fallback.")
+        # PyTorch bundles its own libamdhip64; two HIP runtimes in one process break whichever
+        # initialises second (torch.cuda.is_available() turns False).  Importing torch first makes
+        # libseirhip's libamdhip64 dependency resolve to the runtime torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:                           # pragma: no cover - torch-free hosts
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)       # AttributeError if the .so is stale

@@ -532,7 +532,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     s->use_graph = getenv("SEIR_NO_GRAPH") == nullptr;
     {
         const char *e = getenv("SEIR_CHAIN_GROUPS");
-        int g = e ? atoi(e) : (B >= 4 ? 4 : B);
+        int g = e ? atoi(e) : 1;     // measured: concurrent graphs on several streams do not overlap profitably
         if (g < 1) g = 1;
         if (g > B) g = B;
         s->ngroups = g;

@@ -46,7 +46,8 @@ def test_cli_end_to_end_ni11(tmp_path):
         assert 0.4 < acc <= 1.0, acc
         for key in ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I"):
             a = f.read(f"/results/{key}/is_accepted").mean()
-            assert 0.01 < a < 0.99, (key, a)
+            # with T=32 and dmax=84 most time-moves land outside [0,T) and are auto-rejected
+            assert 0.001 < a < 0.99, (key, a)
         seir = f.read("/samples/seir")
         assert np.array_equal(seir[-1][..., 2], events[..., 2])      # removals are data
         g0 = f.read("/samples/gamma0")[1825:]
