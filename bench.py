@@ -160,6 +160,13 @@ def main():
     M, T, P = cov.M, cov.T, model.P
     alg_bytes = B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
     achieved = alg_bytes / (grad_ms * 1e-3) / 1e9
+    # HBM-side traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this
+    # process): FETCH_SIZE x the gfx950 calibration factor + WRITE_SIZE, same workload and batch.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if a.workload == "uk380" and B == 8 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["k_se<true,1>"]["traffic_bytes_per_launch"]
+        traffic_src = "profiles/r01_pmc_summary.json"
 
     # secondary metric: full log_prob evaluations/sec through the stateless C-ABI
     dev = torch.device("cuda", local)
@@ -194,7 +201,7 @@ def main():
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"kernel": "k_se<GRAD=true,SRC=planes> (S->E term + gradient sums, all chains)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": 1e3 * grad_ms,
                          "launches_per_sweep": 17},
             "log_prob_evals_per_sec": evals,
