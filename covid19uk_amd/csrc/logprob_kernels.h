@@ -364,13 +364,15 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
         colbuf[wave][lane] = colacc;
         // row sums: lane (r = lane>>3, s = lane&7) adds the 8 entries j*8+s of row r, then the
         // 8 lanes of a row combine by shuffles -- one LDS transpose instead of SE_RW wave reductions
-        static_assert(SE_RW == 8, "row-sum transpose assumes 8 rows per wave");
-        const int rr_ = lane >> 3, ss = lane & 7;
+        constexpr int LPR = WAVE / SE_RW;                 // lanes per row; each adds SE_RW entries
+        static_assert(SE_RW == 4 || SE_RW == 8 || SE_RW == 16, "rows per wave");
+        const int rr_ = lane / LPR, ss = lane % LPR;
         const double *src = myrow + rr_ * SE_RS + ss;
-        double v = ((src[0] + src[8]) + (src[16] + src[24])) + ((src[32] + src[40]) + (src[48] + src[56]));
-        v += __shfl_xor(v, 1, WAVE);
-        v += __shfl_xor(v, 2, WAVE);
-        v += __shfl_xor(v, 4, WAVE);
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < SE_RW; j += 2) v += src[j * LPR] + src[(j + 1) * LPR];
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, WAVE);
         if (ss == 0) w.Rpart[((size_t)b * d.ntc + blockIdx.x) * d.Mp + m0 + rr_] = v;
     }
     __syncthreads();

@@ -1,0 +1,498 @@
+// Event-update proposal + finalisation kernel (k_move_pa2) of the Metropolis-within-Gibbs sweep.
+//
+// One MH event update = [finalize the previous proposal | draw the next one] (this kernel, grid
+// (nrb_d, B)) followed by k_move_delta (log-likelihood ratio over the touched cells).  The proposal
+// is a latency chain executed by block 0 of each chain, so it is written to minimise dependent
+// global round trips: the m metapopulations of a proposal are processed together (their rows staged
+// in LDS, one scan per row), uniforms are drawn by one lane each and broadcast through LDS, the
+// per-metapopulation scalar work runs on one lane of different waves in parallel, barriers order
+// LDS traffic only.  Semantics, RNG slots and the arithmetic of every term are those of the first
+// implementation (k_move_pa / propose() in sampler_kernels.h), against which it was validated.
+//
+// Tried and dropped (r01): running the whole MultiScan phase as ONE persistent launch, one
+// workgroup per chain.  It removes 40 launches per sweep but a single CU cannot carry the E->I
+// band (M x <=84 days x m cells, 60-120 us per update against 11 us spread over 48 workgroups)
+// and the fused kernel spilled; measured 1.22-1.34 ms per sweep against 1.07 ms for this split form.
+#pragma once
+#include "sampler_kernels.h"
+
+namespace seir {
+
+constexpr int MVB = 512;              // threads
+constexpr int MVW = MVB / WAVE;       // waves
+constexpr int MVU = 4;                // cells in flight per thread in the band loops
+
+struct MvShared {
+    Move mv;
+    int acc;
+    int sel[MMAX];
+    int ired[MVW * 4];
+    double dred[MVW * 2];
+    double u[2 * MMAX][2];            // uniforms of draw slots 0..2*MMAX-1
+    double logq_part[MMAX];
+    int pend_valid[MMAX];
+};
+
+// exclusive prefix over the block (thread order); sh [MVW]
+__device__ __forceinline__ int mv_excl_scan(int v, int *sh, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v, lane);
+    lds_barrier();
+    if (lane == 63) sh[wave] = inc;
+    lds_barrier();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < MVW; ++j) { const int x = sh[j]; tot += x; if (j < wave) base += x; }
+    total = tot;
+    return base + inc - v;
+}
+
+template <int NV>
+__device__ __forceinline__ void mv_minv(int (&v)[NV], int *sh) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] = min(v[k], __shfl_xor(v[k], o, WAVE));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lds_barrier();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sh[wave * NV + k] = v[k];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        int x = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < MVW; ++j) x = min(x, sh[j * NV + k]);
+        v[k] = x;
+    }
+}
+
+__device__ __forceinline__ void mv_sum2(double &a, double &b2, double *sh) {
+    a = wave_sum(a); b2 = wave_sum(b2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lds_barrier();
+    if (lane == 0) { sh[wave * 2] = a; sh[wave * 2 + 1] = b2; }
+    lds_barrier();
+    double x = 0.0, y = 0.0;
+#pragma unroll
+    for (int j = 0; j < MVW; ++j) { x += sh[j * 2]; y += sh[j * 2 + 1]; }
+    a = x; b2 = y;
+}
+
+// arrays the proposal works from
+struct MvLds {
+    const int *rt;         // [2][rstride] row totals of S->E / E->I events (global)
+    int rstride;
+    int *rg;               // [M] events of the target transition inside the occult range (LDS)
+    int *rk, *rsrc, *rdst; // [MMAX][T+1] staged rows (LDS): target events, compartments either side at start of day
+};
+
+// Change of the S->E term of a cell whose F moves by dF while its own state is unchanged:
+//   k [L(r1) - L(r0)] - (S-k)(r1 - r0),  L(r) = log(1-exp(-r)),  r1 = r0 + a.
+// In the small-rate regime L(r1)-L(r0) = log(r1/r0) + g(r1) - g(r0) with log(r1/r0) = 2 atanh(z),
+// z = a/(2 r0 + a): one reciprocal and two short polynomials instead of two table logs, and more
+// accurate than differencing them.
+__device__ __forceinline__ double band_delta(double S, double I, double K0, double F, double dF, double ee,
+                                             double psiW, double floor_dt, double dt, const double2 *ltab) {
+    const double r0 = ee * (I + psiW * F) * dt + floor_dt;
+    const double a = ee * psiW * dF * dt;
+    const double r1 = r0 + a;
+    double out = -(S - K0) * a;
+    if (K0 != 0.0) {
+        const double z = a * fast_rcp(r0 + r1);
+        double dL;
+        if (r0 >= L1ME_SERIES_MIN && r1 >= L1ME_SERIES_MIN && r0 <= L1ME_SERIES_MAX && r1 <= L1ME_SERIES_MAX &&
+            fabs(z) <= 0.1) {
+            const double z2 = z * z;
+            const double at = z * (2.0 + z2 * (0.66666666666666663 + z2 * (0.4 + z2 * (0.2857142857142857 + z2 * (0.22222222222222221 +
+                              z2 * (0.18181818181818182 + z2 * (0.15384615384615385 + z2 * 0.13333333333333333)))))));
+            const double a2 = r0 * r0, b2 = r1 * r1;
+            const double g0 = r0 * (-0.5 + r0 * (4.1666666666666664e-2 - a2 * (3.4722222222222224e-4 - a2 * (5.5114638447971785e-6 - a2 * 1.0333994708994709e-7))));
+            const double g1 = r1 * (-0.5 + r1 * (4.1666666666666664e-2 - b2 * (3.4722222222222224e-4 - b2 * (5.5114638447971785e-6 - b2 * 1.0333994708994709e-7))));
+            dL = at + (g1 - g0);
+        } else {
+            dL = log1mexp(r1, ltab) - log1mexp(r0, ltab);
+        }
+        out += K0 * dL;
+    }
+    return out;
+}
+
+__device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
+                                  MoveSpec spec, MvShared &sm, const MvLds &L) {
+    Move &mv = sm.mv;
+    const int tid = threadIdx.x, M = d.M, T = d.T, T1 = T + 1;
+    const RngKey key = rng_key(s, ch, b);
+    const uint32_t stream = RS_MOVE_BASE + (uint32_t)(spec.scan * 4 + spec.slot);
+    const int tgt = spec.tgt;
+    // uniforms: one lane per draw slot (slot 15 = the accept uniform), broadcast through LDS
+    if (tid < 2 * MMAX) rng_uniform2(key, stream, (uint32_t)tid, sm.u[tid][0], sm.u[tid][1]);
+    if (tid == 64) {
+        mv.valid = 1; mv.n = 0; mv.tgt = tgt; mv.kind = spec.kind; mv.slot = spec.slot;
+        mv.logq = 0.0; mv.any_dI = 0; mv.LO = T; mv.HI = -1;
+        for (int j = 0; j < MMAX; ++j) { mv.tm[j] = mv.tt[j] = mv.tdt[j] = mv.tx[j] = 0; mv.b[j] = -1; sm.pend_valid[j] = -1; }
+        double ua, ub;
+        rng_uniform2(key, stream, 15u, ua, ub);
+        mv.logu = cold_log(ua);
+    }
+    const int per = (M + MVB - 1) / MVB;
+    const int r_lo = tid * per, r_hi = min(M, r_lo + per);
+
+    if (spec.kind == 0) {
+        // ---- UncalibratedEventTimesUpdate ---------------------------------
+        const int *rt = L.rt + tgt * L.rstride;
+        int c = 0;
+        for (int m = r_lo; m < r_hi; ++m) c += rt[m] > 0 ? 1 : 0;
+        int H;
+        const int before = mv_excl_scan(c, sm.ired, H);          // also publishes sm.u / mv init
+        const int nsel = min(min(s.mmax, MMAX), H);
+        // positions of the nsel distinct hot rows (every thread computes the same values)
+        int pos[MMAX], chosen[MMAX];
+        for (int j = 0; j < nsel; ++j) {
+            int p = rng_index(sm.u[2 * j][0], H - j);
+            for (int a = 0; a < j; ++a)
+                if (p >= chosen[a]) ++p;
+            int ins = j;
+            while (ins > 0 && chosen[ins - 1] > p) { chosen[ins] = chosen[ins - 1]; --ins; }
+            chosen[ins] = p;
+            pos[j] = p;
+        }
+        for (int j = 0; j < nsel; ++j)
+            if (pos[j] >= before && pos[j] < before + c) {
+                int k = pos[j] - before;
+                for (int m = r_lo; m < r_hi; ++m)
+                    if (rt[m] > 0) {
+                        if (k == 0) { sm.sel[j] = m; break; }
+                        --k;
+                    }
+            }
+        lds_barrier();
+        // stage the chosen rows: k[t], source and destination compartments at the start of day t in [0,T]
+        for (int idx = tid; idx < nsel * T1; idx += MVB) {
+            const int j = idx / T1, t = idx - j * T1;
+            const size_t rowoff = ((size_t)b * d.Mp + sm.sel[j]) * d.Tp;
+            L.rk[idx] = t < T ? w.K[tgt][rowoff + t] : 0;
+            L.rsrc[idx] = comp_start(d, w, rowoff, tgt, t);
+            L.rdst[idx] = comp_start(d, w, rowoff, tgt + 1, t);
+        }
+        __syncthreads();
+        // day of each row: the floor(u D)-th day with events
+        const int tper = (T + MVB - 1) / MVB;
+        const int t_lo = tid * tper, t_hi = min(T, t_lo + tper);
+        int Dj[MMAX], tj[MMAX];
+        for (int j = 0; j < nsel; ++j) {
+            const int *kr = L.rk + j * T1;
+            int cc = 0;
+            for (int t = t_lo; t < t_hi; ++t) cc += kr[t] > 0 ? 1 : 0;
+            int D;
+            const int bef = mv_excl_scan(cc, sm.ired, D);
+            const int r = rng_index(sm.u[2 * j][1], D);
+            if (r >= bef && r < bef + cc) {
+                int k = r - bef;
+                for (int t = t_lo; t < t_hi; ++t)
+                    if (kr[t] > 0) {
+                        if (k == 0) { sm.sel[j] = (sm.sel[j] & 0xffff) | (t << 16); break; }
+                        --k;
+                    }
+            }
+            Dj[j] = D;
+        }
+        lds_barrier();
+        // bounds: min over (lo,hi] of the compartment that loses x, and of the one that gains it
+        int mins[2 * MMAX];
+        int mj[MMAX], dj[MMAX], t2j[MMAX];
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) {
+            mins[2 * j] = mins[2 * j + 1] = 0x7fffffff;
+            if (j >= nsel) continue;
+            mj[j] = sm.sel[j] & 0xffff; tj[j] = sm.sel[j] >> 16;
+            const int v = rng_index(sm.u[2 * j + 1][0], 2 * s.dmax);
+            dj[j] = v < s.dmax ? v - s.dmax : v - s.dmax + 1;
+            t2j[j] = tj[j] + dj[j];
+            if (t2j[j] < 0 || t2j[j] >= T) continue;             // out of range: rejected below
+            const int lo = min(tj[j], t2j[j]), hi = max(tj[j], t2j[j]);
+            const bool later = dj[j] > 0;
+            const int *decp = (later ? L.rdst : L.rsrc) + j * T1, *incp = (later ? L.rsrc : L.rdst) + j * T1;
+            for (int tau = lo + 1 + tid; tau <= hi; tau += MVB) {
+                mins[2 * j] = min(mins[2 * j], decp[tau]);
+                mins[2 * j + 1] = min(mins[2 * j + 1], incp[tau]);
+            }
+        }
+        mv_minv<2 * MMAX>(mins, sm.ired);
+        // one lane per metapopulation finishes its update
+        const int jj = tid >> 6;
+        if ((tid & 63) == 0 && jj < nsel) {
+            const int j = jj, m = mj[j], t = tj[j], delta = dj[j], t2 = t2j[j];
+            if (t2 < 0 || t2 >= T) {
+                sm.pend_valid[j] = 0;
+                mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = 0;
+                sm.logq_part[j] = 0.0;
+            } else {
+                const bool later = delta > 0;
+                const bool dec_unbounded = !later && tgt == 0;   // S: prev_event_id None -> no bound
+                const bool inc_unbounded = later && tgt == 0;
+                const int min_dec = dec_unbounded ? 0x7fffffff : mins[2 * j];
+                const int min_inc = mins[2 * j + 1];
+                const int *kr = L.rk + j * T1;
+                const int kt = kr[t], kt2 = kr[t2], D = Dj[j];
+                const int xmax = max(0, min(min(s.nmax, kt), min_dec));
+                const int x = rng_index(sm.u[2 * j + 1][1], xmax + 1);
+                const int Dn = D - ((x > 0 && x == kt) ? 1 : 0) + ((x > 0 && kt2 == 0) ? 1 : 0);
+                const long long binc = inc_unbounded ? 0x7fffffffLL : (long long)min_inc + x;
+                const int xmax_r = (int)max(0LL, min((long long)min(s.nmax, kt2 + x), binc));
+                sm.logq_part[j] = (-cold_log((double)Dn) - cold_log((double)(xmax_r + 1))) -
+                                  (-cold_log((double)D) - cold_log((double)(xmax + 1)));
+                sm.pend_valid[j] = 1;
+                mv.m[j] = m; mv.a[j] = t; mv.b[j] = t2; mv.dka[j] = -x; mv.dkb[j] = x;
+                mv.lo[j] = min(t, t2); mv.hi[j] = max(t, t2);
+                mv.dsrc[j] = later ? x : -x;
+                mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = x;
+            }
+        }
+        lds_barrier();
+        if (tid == 0) {
+            // compact the in-range updates (order preserved) and combine the correction
+            int n = 0;
+            double lq = 0.0;
+            for (int j = 0; j < nsel; ++j) {
+                if (sm.pend_valid[j] == 0) { mv.valid = 0; continue; }
+                lq += sm.logq_part[j];
+                if (n != j) {
+                    mv.m[n] = mv.m[j]; mv.a[n] = mv.a[j]; mv.b[n] = mv.b[j]; mv.dka[n] = mv.dka[j];
+                    mv.dkb[n] = mv.dkb[j]; mv.lo[n] = mv.lo[j]; mv.hi[n] = mv.hi[j]; mv.dsrc[n] = mv.dsrc[j];
+                }
+                mv.LO = min(mv.LO, mv.lo[n]); mv.HI = max(mv.HI, mv.hi[n]);
+                if (tgt == 1 && mv.dsrc[n] != 0) mv.any_dI = 1;
+                ++n;
+            }
+            mv.n = n;
+            mv.logq = lq;
+        }
+    } else {
+        // ---- UncalibratedOccultUpdate --------------------------------------
+        const int R = s.tr_hi - s.tr_lo;
+        const int *rg = L.rg;
+        int c = 0;
+        for (int m = r_lo; m < r_hi; ++m) c += rg[m] > 0 ? 1 : 0;
+        int Hd;
+        const int before = mv_excl_scan(c, sm.ired, Hd);
+        const double u_br = sm.u[0][0], u_m = sm.u[0][1], u_t = sm.u[1][0], u_x = sm.u[1][1];
+        const bool is_del = (u_br < 0.5) && Hd > 0;
+        if (!is_del) {
+            if (tid == 0) sm.sel[0] = rng_index(u_m, M);
+        } else {
+            const int r = rng_index(u_m, Hd);
+            if (r >= before && r < before + c) {
+                int k = r - before;
+                for (int m = r_lo; m < r_hi; ++m)
+                    if (rg[m] > 0) {
+                        if (k == 0) { sm.sel[0] = m; break; }
+                        --k;
+                    }
+            }
+        }
+        lds_barrier();
+        const int m = sm.sel[0];
+        const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
+        for (int t = tid; t < T1; t += MVB) {
+            L.rk[t] = t < T ? w.K[tgt][rowoff + t] : 0;
+            L.rsrc[t] = comp_start(d, w, rowoff, tgt, t);
+            L.rdst[t] = comp_start(d, w, rowoff, tgt + 1, t);
+        }
+        __syncthreads();
+        // hot days of row m inside the range; the day of a delete is the floor(u Dm)-th of them
+        int cc = 0;
+        const int rper = (R + MVB - 1) / MVB;
+        const int i_lo = tid * rper, i_hi = min(R, i_lo + rper);
+        for (int i = i_lo; i < i_hi; ++i) cc += L.rk[s.tr_lo + i] > 0 ? 1 : 0;
+        int Dm;
+        const int bef = mv_excl_scan(cc, sm.ired, Dm);
+        if (is_del) {
+            const int r = rng_index(u_t, Dm);
+            if (r >= bef && r < bef + cc) {
+                int k = r - bef;
+                for (int i = i_lo; i < i_hi; ++i)
+                    if (L.rk[s.tr_lo + i] > 0) {
+                        if (k == 0) { sm.sel[1] = s.tr_lo + i; break; }
+                        --k;
+                    }
+            }
+        } else if (tid == 0) {
+            sm.sel[1] = s.tr_lo + rng_index(u_t, R);
+        }
+        lds_barrier();
+        const int t = sm.sel[1];
+        int mins[2] = {0x7fffffff, 0x7fffffff};
+        for (int tau = t + 1 + tid; tau <= T; tau += MVB) { mins[0] = min(mins[0], L.rsrc[tau]); mins[1] = min(mins[1], L.rdst[tau]); }
+        mv_minv<2>(mins, sm.ired);
+        if (tid == 0) {
+            const int min_src = tgt == 0 ? 0x7fffffff : mins[0], min_dst = mins[1];
+            const int kt = L.rk[t], rt_m = rg[m];
+            const double lM = cold_log((double)M), lR = cold_log((double)R), l2 = 0.6931471805599453;
+            int x;
+            if (!is_del) {
+                const int xmax = max(0, min(s.occult_nmax, min_src));
+                x = rng_index(u_x, xmax + 1);
+                const double qf = (Hd > 0 ? -l2 : 0.0) - lM - lR - cold_log((double)(xmax + 1));
+                const int Hd2 = Hd + ((rt_m == 0 && x > 0) ? 1 : 0);
+                const int Dm2 = Dm + ((kt == 0 && x > 0) ? 1 : 0);
+                const long long bd = (long long)min_dst + x;
+                const int xmax_r = (int)max(0LL, min((long long)min(s.occult_nmax, kt + x), bd));
+                const double qr = (Hd2 > 0 && kt + x > 0)
+                                      ? -l2 - cold_log((double)Hd2) - cold_log((double)Dm2) - cold_log((double)(xmax_r + 1))
+                                      : -INFINITY;
+                mv.logq = qr - qf;
+                mv.dka[0] = x; mv.dsrc[0] = -x;
+            } else {
+                const int xmax = max(0, min(min(s.occult_nmax, kt), min_dst));
+                x = rng_index(u_x, xmax + 1);
+                const double qf = -l2 - cold_log((double)Hd) - cold_log((double)Dm) - cold_log((double)(xmax + 1));
+                const int Hd2 = Hd - ((x > 0 && rt_m == x) ? 1 : 0);
+                const long long bs = tgt == 0 ? 0x7fffffffLL : (long long)min_src + x;
+                const int xmax_r = (int)max(0LL, min((long long)s.occult_nmax, bs));
+                const double qr = (Hd2 > 0 ? -l2 : 0.0) - lM - lR - cold_log((double)(xmax_r + 1));
+                mv.logq = qr - qf;
+                mv.dka[0] = -x; mv.dsrc[0] = x;
+            }
+            mv.n = 1;
+            mv.m[0] = m; mv.a[0] = t; mv.b[0] = -1; mv.dkb[0] = 0;
+            mv.lo[0] = t; mv.hi[0] = T - 1;
+            mv.LO = t; mv.HI = T - 1;
+            mv.any_dI = (tgt == 1 && x != 0) ? 1 : 0;
+            mv.tm[0] = m; mv.tt[0] = t; mv.tdt[0] = is_del ? -1 : 1; mv.tx[0] = x;
+        }
+    }
+    lds_barrier();
+}
+
+// row totals of the target transition inside the occult range, for every row, into LDS
+__device__ __forceinline__ void range_totals_to_lds(const Dims &d, const Work &w, const SamplerCfg &s, int b, int tgt,
+                                                    int *rg) {
+    const int R = s.tr_hi - s.tr_lo, n = d.M * R;
+    for (int m = threadIdx.x; m < d.M; m += MVB) rg[m] = 0;
+    lds_barrier();
+    for (int base = threadIdx.x; base < n; base += MVB * MVU) {
+        int v[MVU], row[MVU];
+#pragma unroll
+        for (int k = 0; k < MVU; ++k) {
+            const int idx = base + k * MVB;
+            v[k] = 0; row[k] = 0;
+            if (idx < n) {
+                const int m = idx / R, t = s.tr_lo + idx - m * R;
+                row[k] = m;
+                v[k] = w.K[tgt][((size_t)b * d.Mp + m) * d.Tp + t];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MVU; ++k)
+            if (v[k]) atomicAdd(&rg[row[k]], v[k]);
+    }
+    __syncthreads();
+}
+
+// k_move_pa2: (1) finalize the pending proposal -- MetropolisHastings accept test
+// (mcmc_kernel_factory.py:72,99), F band update by every block, row-local state update and trace
+// by block 0 -- then (2) block 0 draws the next proposal.  next.kind < 0: finalize only.
+// grid (nrb_d, B), MVB threads.  The pending descriptor is read from buffer pbuf, the next one
+// written to pbuf^1 (late blocks must not see the new one).
+__global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
+                                                  int have_prev, int pbuf) {
+    extern __shared__ int dyn_i[];                     // block 0: rg [M] | rk, rsrc, rdst [MMAX][T+1]
+    __shared__ MvShared sm;
+    __shared__ Move pend;
+    __shared__ int s_acc;
+    __shared__ double s_dth, s_dcn;
+    const int b = d.b0 + blockIdx.y, tid = threadIdx.x;
+    const int M = d.M, T = d.T;
+    if (have_prev) {
+        if (tid == 0) pend = ch.mv[(size_t)pbuf * s.B + b];
+        double dth = 0.0, dcn = 0.0;
+        for (int i = tid; i < s.nrb_d; i += MVB) {
+            dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
+            dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
+        }
+        mv_sum2(dth, dcn, sm.dred);
+        if (tid == 0) {
+            const double ratio = dth + dcn + pend.logq;
+            s_acc = (pend.valid && pend.logu < ratio) ? 1 : 0;   // NaN -> reject
+            s_dth = dth; s_dcn = dcn;
+        }
+        __syncthreads();
+        const Move &mv = pend;
+        if (s_acc && mv.any_dI) {
+            // F[j][t] += sum_i Cstar[j][m_i] dI_i / N_{m_i}  on each update's day window
+            const int rows_per_blk = (M + s.nrb_d - 1) / s.nrb_d;
+            const int r_lo = blockIdx.x * rows_per_blk, r_hi = min(M, r_lo + rows_per_blk);
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int j = r_lo + wave; j < r_hi; j += MVW) {
+                double coef[MMAX];
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                                       : 0.0;
+                double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
+                for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
+                    double dF = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MMAX; ++i)
+                        if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+                    if (dF != 0.0) Fr[t] += dF;
+                }
+            }
+        }
+        if (blockIdx.x == 0) {
+            if (s_acc) {
+                for (int i = 0; i < mv.n; ++i) {
+                    const size_t rowoff = ((size_t)b * d.Mp + mv.m[i]) * d.Tp;
+                    const int src = mv.tgt, dst = mv.tgt + 1;
+                    for (int t = mv.lo[i] + 1 + tid; t <= mv.hi[i]; t += MVB) {
+                        w.St[src][rowoff + t] += mv.dsrc[i];
+                        w.St[dst][rowoff + t] -= mv.dsrc[i];
+                        if (mv.tgt == 1) w.Dir[(size_t)b * d.Tp + t] -= (double)mv.dsrc[i];
+                    }
+                    if (tid == 0) {
+                        w.K[mv.tgt][rowoff + mv.a[i]] += mv.dka[i];
+                        if (mv.b[i] >= 0) w.K[mv.tgt][rowoff + mv.b[i]] += mv.dkb[i];
+                        w.rowtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += mv.dka[i] + mv.dkb[i];
+                    }
+                    __syncthreads();     // two updates may touch the same Dir[t]
+                }
+            }
+            if (tid == 0) {
+                double *hs = ch.hs + (size_t)b * NHS;
+                if (s_acc) { hs[HS_LP_THETA] += s_dth; hs[HS_LP_CONST] += s_dcn; }
+                const unsigned slot = ch.sweep[b] - ch.slot0[0];
+                if (slot < (unsigned)s.cap) {
+                    double *tr = ch.tr_mv + (((size_t)slot * s.B + b) * 4 + mv.slot) * NMVTR;
+                    tr[0] = (double)s_acc;
+                    tr[1] = hs[HS_LP_THETA] + hs[HS_LP_CONST];
+                    for (int j = 0; j < MMAX; ++j) {
+                        tr[2 + j] = mv.tm[j]; tr[2 + MMAX + j] = mv.tt[j];
+                        tr[2 + 2 * MMAX + j] = mv.tdt[j]; tr[2 + 3 * MMAX + j] = mv.tx[j];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x == 0 && next.kind >= 0) {
+        MvLds L{};
+        L.rt = w.rowtot + (size_t)b * 2 * d.Mp;
+        L.rstride = d.Mp;
+        L.rg = dyn_i;
+        L.rk = dyn_i + M;
+        L.rsrc = L.rk + MMAX * (T + 1);
+        L.rdst = L.rsrc + MMAX * (T + 1);
+        if (next.kind == 1) range_totals_to_lds(d, w, s, b, next.tgt, L.rg);
+        mv_propose(d, w, s, ch, b, next, sm, L);
+        if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm.mv;
+    }
+}
+
+inline size_t k_move_pa2_lds_bytes(const Dims &d) {
+    return sizeof(int) * ((size_t)d.M + 3 * MMAX * (d.T + 1));
+}
+
+}  // namespace seir

@@ -14,6 +14,7 @@
 
 #include "../../include/seir_hip.h"
 #include "sampler_kernels.h"
+#include "moves_kernel.h"
 
 using namespace seir;
 
@@ -464,6 +465,7 @@ struct seir_sampler {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     bool use_graph = true;
+    bool legacy_moves = false;    // SEIR_MOVES=legacy: first implementation of the proposal kernel (k_move_pa)
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
 };
@@ -530,6 +532,10 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     c.nrb_d = (d.M + 7) / 8;
     s->record_events = ds->record_events;
     s->use_graph = getenv("SEIR_NO_GRAPH") == nullptr;
+    {
+        const char *e = getenv("SEIR_MOVES");
+        s->legacy_moves = e && strcmp(e, "legacy") == 0;
+    }
     {
         const char *e = getenv("SEIR_CHAIN_GROUPS");
         int g = e ? atoi(e) : 1;     // measured: concurrent graphs on several streams do not overlap profitably
@@ -801,20 +807,32 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     }
     launch_se<1>(ctx, l, true);
     launch_hmc(ctx, l, c, s->ch, 2);
-    // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I])
-    const dim3 gm(c.nrb_d, nb);
-    int have_prev = 0, pbuf = 0;
-    for (int scan = 0; scan < c.n_scans; ++scan)
-        for (int slot = 0; slot < 4; ++slot) {
-            const MoveSpec spec{slot >= 2 ? 1 : 0, slot & 1, slot, scan};
-            hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, spec, have_prev, pbuf);
-            pbuf ^= 1;
-            hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf);
-            have_prev = 1;
+    // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
+    // per update [finalize previous | propose] then the log-ratio over the touched cells
+    {
+        const dim3 gm(c.nrb_d, nb);
+        const size_t plds = k_move_pa2_lds_bytes(d);
+        int have_prev = 0, pbuf = 0;
+        for (int scan = 0; scan < c.n_scans; ++scan)
+            for (int slot = 0; slot < 4; ++slot) {
+                const MoveSpec spec{slot >= 2 ? 1 : 0, slot & 1, slot, scan};
+                if (s->legacy_moves)
+                    hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, spec, have_prev,
+                                       pbuf);
+                else
+                    hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
+                                       have_prev, pbuf);
+                pbuf ^= 1;
+                hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf);
+                have_prev = 1;
+            }
+        if (have_prev) {
+            const MoveSpec none{-1, 0, 0, 0};
+            if (s->legacy_moves)
+                hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+            else
+                hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
         }
-    if (have_prev) {
-        const MoveSpec none{-1, 0, 0, 0};
-        hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
     }
     if (s->record_events) hipLaunchKernelGGL(k_record, dim3(32, nb), dim3(256), 0, st, d, ctx->w, c, s->ch);
     hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);

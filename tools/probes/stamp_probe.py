@@ -6,7 +6,7 @@ from covid19uk_amd import synth
 from covid19uk_amd.sampler import ChainSampler
 from covid19uk_amd.seir import SeirModel
 os.environ["SEIR_NO_GRAPH"] = "1"
-cfg = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=0)
+cfg = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=int(os.environ.get("NSCAN", "0")))
 cov = synth.make_covariates("uk380")
 events, init, truth = synth.simulate_epidemic(cov)
 u0 = synth.unconstrain(synth.pack_params(truth, cov.M, cov.T))
@@ -21,5 +21,15 @@ with SeirModel(cov, init, max_chains=B) as model:
         s.reset_trace(); s.run(3); model.sync()
         hs = np.empty((B, 32))
         lib.seir_sampler_debug_hs(s._s, hs.ctypes.data_as(_lib.c_double_p))
-        st = hs[0, 16:26].view(np.uint64).astype(np.int64)
-        print("stamps (10ns ticks) deltas:", np.diff(st) * 10, "ns ; total", (st[-1] - st[0]) * 10, "ns")
+        st = hs[0, 16:32].view(np.uint64)
+        if cfg["num_event_time_updates"] == 0:
+            st = st[:10].astype(np.int64)
+            print("stamps (10ns ticks) deltas:", np.diff(st) * 10, "ns ; total", (st[-1] - st[0]) * 10, "ns")
+        else:
+            names = ["mvSE", "mvEI", "ocSE", "ocEI"]
+            for i, v in enumerate(st):
+                v = int(v)
+                print(f"scan {i // 4} {names[i % 4]}: propose {(v & 0xfffff) / 100:.2f} us, delta {((v >> 20) & 0xfffff) / 100:.2f} us, "
+                      f"apply {((v >> 40) & 0xfffff) / 100:.2f} us, acc {(v >> 60) & 1} valid {(v >> 61) & 1}")
+        tr = s.read_trace(3, events=False)
+        print("accepts", {k: v["is_accepted"][-1].astype(int).tolist() for k, v in tr.moves.items()})
