@@ -28,6 +28,7 @@ enum { SC_PSI = 0, SC_SIG, SC_BETA, SC_G0, SC_G1, SC_A0, SC_S0, SC_S1, SC_PRIOR,
 
 struct Dims {
     int M, T, Mp, Tp, Kp, P, Pp;
+    int Kp0;                // row stride of the padded Cstar [Kp rows used][Kp0 = Mp columns]
     int b0;                 // first chain handled by this launch (chain groups on separate streams)
     int nrb_scan;           // row blocks of k_scan
     int nmt, ntc;           // k_se tiles: Mp/SE_TM row tiles, Tp/64 day chunks
@@ -37,7 +38,7 @@ struct Dims {
 };
 
 struct Consts {
-    const double *Cstar;   // [Mp][Kp]
+    const double *Cstar;   // [Mp][Kp0], Kp0 = Mp: zero-padded, symmetric
     const double *N, *invN, *la;   // [Mp]
     const double *W, *wd;          // [Tp]
     const double *init;            // [Mp][4]
@@ -173,62 +174,91 @@ __global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) {
 }
 
 // ---------------------------------------------------------------------------
-// k_gemm: F[b] = Cstar[Mp x Kp] . Xn[b][Kp x Tp] with v_mfma_f64_16x16x4_f64.
-// Workgroup = one 16-row panel of Cstar staged in LDS (row stride == 2 mod 32
-// doubles: conflict-free ds_read_b64 for the A fragment) x GEMM_TT t-tiles per wave.
-// A: lane l holds A[l&15][l>>4]; B: B[l>>4][l&15]; D: row (l>>4)+4r, col l&15.
+// k_gemm: F[b] = Cstar[Mp x Kp] . Xn[b][Kp x Tp] for all T at once (the matvec of
+// model_spec.py:262 for every day), fp64 on the matrix cores: v_mfma_f64_16x16x4_f64
+// (A: lane l holds A[l&15][l>>4]; B: B[l>>4][l&15]; D: row (l>>4)+4r, col l&15).
+//
+// Workgroup tile 64 (rows) x 64 (days), 4 waves as 2 x 2, each wave a 32 x 32 sub-tile =
+// 2 x 2 MFMA tiles with independent accumulators (4 MFMAs per pair of A and pair of B fragments,
+// back-to-back issue).  K runs in chunks of 64 staged in LDS; the next chunk's global loads are
+// issued into registers before the 64 MFMAs of the current chunk (~1.7 us of matrix work, longer
+// than the load latency) and written to LDS after them.  Cstar is symmetric
+// (C + C^T with a diagonal), so the A chunk is read as Cstar[k][m0..m0+63] -- contiguous rows --
+// and lands in LDS already "transposed" for the A fragment; row stride 80 doubles (== 16 mod 32)
+// makes both fragment reads conflict-free ds_read_b64.
 // ---------------------------------------------------------------------------
-constexpr int GEMM_TT = 2;      // 16-wide t-tiles per wave (share the A fragment)
-constexpr int GEMM_KC = 512;    // K chunk staged in LDS (66 KB at the cap)
+constexpr int GEMM_TM = 64, GEMM_TN = 64, GEMM_KC = 64, GEMM_RS = 80;
 using d4 = __attribute__((ext_vector_type(4))) double;
 
-__host__ __device__ inline int gemm_kc(int Kp) { return Kp < GEMM_KC ? Kp : GEMM_KC; }
-__host__ __device__ inline int gemm_lda(int Kp) { return ((gemm_kc(Kp) + 31) / 32) * 32 + 2; }
+__host__ __device__ inline size_t gemm_lds_bytes() { return (size_t)2 * GEMM_KC * GEMM_RS * sizeof(double); }
 
 __global__ __launch_bounds__(256) void k_gemm(Dims d, Consts c, Work w) {
-    extern __shared__ double lds[];                 // [16][lda]
-    const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * 16;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lda = gemm_lda(d.Kp), kc = gemm_kc(d.Kp);
-    const int tt0 = (blockIdx.x * 4 + wave) * GEMM_TT;     // first 16-wide t tile of this wave
+    extern __shared__ double lds[];                 // [A | B][KC][RS]
+    const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * GEMM_TM, t0 = blockIdx.x * GEMM_TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
     const double *Xb = w.Xn + (size_t)b * d.Mp * d.Tp;
-    const int ar = lane & 15, ak = lane >> 4;
-    d4 acc[GEMM_TT];
-    bool live[GEMM_TT];
+    double *A = lds, *Bm = lds + GEMM_KC * GEMM_RS;
+    // staging: KC rows x 64 columns per matrix = KC*32 double2, KC/8 per thread and matrix
+    constexpr int NST = GEMM_KC / 8;
+    const int sr = tid >> 5, sc2 = (tid & 31) * 2;
+    double2 ra[NST], rb[NST];
+    auto load_chunk = [&](int kb) {
 #pragma unroll
-    for (int j = 0; j < GEMM_TT; ++j) {
-        acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-        live[j] = (tt0 + j) * 16 < d.Tp;
-    }
-    const double *ap = lds + ar * lda + ak;
-    for (int kb = 0; kb < d.Kp; kb += kc) {
-        const int kn = min(kc, d.Kp - kb);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 16 * kn; i += 256) {
-            const int r = i / kn, k = i - r * kn;
-            lds[r * lda + k] = c.Cstar[(size_t)(m0 + r) * d.Kp + kb + k];
-        }
-        __syncthreads();
-        const double *bp = Xb + (size_t)(kb + ak) * d.Tp + tt0 * 16 + ar;
-#pragma unroll 4
-        for (int k0 = 0; k0 < kn; k0 += 4) {
-            const double a = ap[k0];
-            const double *bk = bp + (size_t)k0 * d.Tp;
-#pragma unroll
-            for (int j = 0; j < GEMM_TT; ++j) {
-                const double bv = live[j] ? bk[j * 16] : 0.0;
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[j], 0, 0, 0);
+        for (int i = 0; i < NST; ++i) {
+            const int k = kb + sr + 8 * i;
+            if (k < d.Kp) {
+                ra[i] = *(const double2 *)(c.Cstar + (size_t)k * d.Kp0 + m0 + sc2);
+                rb[i] = *(const double2 *)(Xb + (size_t)k * d.Tp + t0 + sc2);
+            } else {
+                ra[i] = make_double2(0.0, 0.0);
+                rb[i] = make_double2(0.0, 0.0);
             }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            *(double2 *)(A + (sr + 8 * i) * GEMM_RS + sc2) = ra[i];
+            *(double2 *)(Bm + (sr + 8 * i) * GEMM_RS + sc2) = rb[i];
+        }
+    };
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int ar = lane & 15, ak = lane >> 4;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int kb = 0; kb < d.Kp; kb += GEMM_KC) {
+        const bool more = kb + GEMM_KC < d.Kp;
+        if (more) load_chunk(kb + GEMM_KC);          // in flight behind the 64 MFMAs of this chunk
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KC; kk += 4) {
+            const double *ap = A + (kk + ak) * GEMM_RS + wr * 32 + ar;
+            const double *bp = Bm + (kk + ak) * GEMM_RS + wc * 32 + ar;
+            const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();                             // every wave is done with the chunk in LDS
+        if (more) {
+            store_chunk();
+            __syncthreads();
         }
     }
     double *Fb = w.F + (size_t)b * d.Mp * d.Tp;
 #pragma unroll
-    for (int j = 0; j < GEMM_TT; ++j) {
-        if (!live[j]) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            Fb[(size_t)(m0 + ak + 4 * r) * d.Tp + (tt0 + j) * 16 + ar] = acc[j][r];
-    }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Fb[(size_t)(m0 + wr * 32 + i * 16 + ak + 4 * r) * d.Tp + t0 + wc * 32 + j * 16 + ar] = acc[i][j][r];
 }
 
 // ---------------------------------------------------------------------------

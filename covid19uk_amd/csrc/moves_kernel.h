@@ -430,7 +430,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
                 double coef[MMAX];
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)
-                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
                                        : 0.0;
                 double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
                 for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {

@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
                 double coef[MMAX];
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)      // Cstar is symmetric: read row m_i contiguously
-                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
                                        : 0.0;
                 for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
                     double dF = 0.0;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
 #pragma unroll
             for (int i = 0; i < MMAX; ++i)
                 coef[i] = (i < mv.n && mv.tgt == 1)
-                              ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                              ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
                               : 0.0;
             for (int t = mv.LO + (int)threadIdx.x; t <= mv.HI; t += 256) {
                 double dF = 0.0;
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256) void k_move_pa(Dims d, Consts c, Work w, Sampl
                 double coef[MMAX];
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)
-                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
                                        : 0.0;
                 double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
                 for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {

@@ -96,6 +96,7 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
     d.Mp = ceil_to(M, 64);
     d.Tp = ceil_to(T, 64);
     d.Kp = ceil_to(M, 4);
+    d.Kp0 = d.Mp;
     d.P = 6 + (T - 1) + M;
     d.Pp = d.P;
     d.b0 = 0;
@@ -133,16 +134,20 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_lfact), lf, sizeof(lf)));
 
     // padded constants
-    std::vector<double> Cs((size_t)d.Mp * d.Kp, 0.0), N(d.Mp, 1.0), invN(d.Mp, 0.0), la(d.Mp, 0.0),
+    std::vector<double> Cs((size_t)d.Mp * d.Kp0, 0.0), N(d.Mp, 1.0), invN(d.Mp, 0.0), la(d.Mp, 0.0),
         W(d.Tp, 0.0), wd(d.Tp, 0.0), init((size_t)d.Mp * 4, 0.0);
     for (int m = 0; m < M; ++m) {
-        for (int j = 0; j < M; ++j) Cs[(size_t)m * d.Kp + j] = ds->Cstar[(size_t)m * M + j];
+        for (int j = 0; j < M; ++j) Cs[(size_t)m * d.Kp0 + j] = ds->Cstar[(size_t)m * M + j];
         if (!(ds->N[m] > 0.0)) return fail(SEIR_ERR_INVALID, "N[%d] must be positive", m);
         N[m] = ds->N[m];
         invN[m] = 1.0 / ds->N[m];
         la[m] = ds->log_area_c[m];
         for (int s = 0; s < 4; ++s) init[(size_t)m * 4 + s] = ds->init_state[(size_t)m * 4 + s];
     }
+    for (int m = 0; m < M; ++m)          // C + C^T with a diagonal is symmetric (model_spec.py:216-219); k_gemm relies on it
+        for (int j = 0; j < m; ++j)
+            if (ds->Cstar[(size_t)m * M + j] != ds->Cstar[(size_t)j * M + m])
+                return fail(SEIR_ERR_INVALID, "Cstar must be symmetric (entry %d,%d)", m, j);
     for (int t = 0; t < T; ++t) { W[t] = ds->W[t]; wd[t] = ds->weekday_c[t]; }
     std::vector<int> qrow(M + 1, 0), qcol;
     std::vector<double> qval;
@@ -266,9 +271,8 @@ static void launch_colreduce(seir_ctx *ctx, const LaunchCfg &l) {
 }
 static void launch_gemm(seir_ctx *ctx, const LaunchCfg &l) {
     const Dims &d = l.d;
-    const int ntt = d.Tp / 16, per_wg = 4 * GEMM_TT;
-    hipLaunchKernelGGL(k_gemm, dim3((ntt + per_wg - 1) / per_wg, d.Mp / 16, l.nb), dim3(256),
-                       (size_t)16 * gemm_lda(d.Kp) * sizeof(double), l.st, d, ctx->c, ctx->w);
+    hipLaunchKernelGGL(k_gemm, dim3(d.Tp / GEMM_TN, d.Mp / GEMM_TM, l.nb), dim3(256), gemm_lds_bytes(), l.st, d,
+                       ctx->c, ctx->w);
 }
 static void launch_params(seir_ctx *ctx, const LaunchCfg &l, const double *u) {
     hipLaunchKernelGGL(k_params, dim3(l.nb), dim3(256), 0, l.st, l.d, ctx->c, ctx->w, u);
