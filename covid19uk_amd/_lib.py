@@ -75,6 +75,7 @@ _SIGNATURES = {
     "seir_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.POINTER(ctypes.c_float)]),
     "seir_selftest_math": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [c_double_p] * 4),
+    "seir_reproduction_number": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
     "seir_sampler_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SeirSamplerDesc), c_void_pp]),
     "seir_sampler_destroy": (None, [ctypes.c_void_p]),
     "seir_sampler_set_state": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),

@@ -15,6 +15,7 @@
 #include "../../include/seir_hip.h"
 #include "sampler_kernels.h"
 #include "moves_kernel.h"
+#include "rt_kernels.h"
 
 using namespace seir;
 
@@ -448,6 +449,35 @@ extern "C" int seir_selftest_math(seir_ctx *ctx, int32_t n, const double *x, dou
     HIP_TRY(hipMemcpy(inv, dx + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lf, dx + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(dx));
+    return 0;
+}
+
+extern "C" int seir_reproduction_number(seir_ctx *ctx, int32_t n, const double *theta, const double *events,
+                                        double *R_it) {
+    int rc = check_batch(ctx, 1);
+    if (rc) return rc;
+    if (n < 1 || !theta || !events || !R_it) return fail(SEIR_ERR_INVALID, "bad arguments");
+    const Dims &d = ctx->d;
+    const int Bm = ctx->Bmax;
+    double *rit_dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&rit_dev, sizeof(double) * Bm * d.T * d.M));
+    for (int s0 = 0; s0 < n; s0 += Bm) {
+        const int nb = std::min(Bm, n - s0);
+        HIP_TRY(hipMemcpyAsync(ctx->u_stage, theta + (size_t)s0 * d.P, sizeof(double) * nb * d.P,
+                               hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->ev_stage, events + (size_t)s0 * d.M * d.T * 3, sizeof(double) * nb * d.M * d.T * 3,
+                               hipMemcpyHostToDevice, ctx->stream));
+        launch_scan<0>(ctx, whole(ctx, nb), ctx->ev_stage);               // KS = (k_se, S - k_se): S_it
+        hipLaunchKernelGGL(k_rt_tables, dim3(nb), dim3(256), 0, ctx->stream, d, ctx->w, ctx->u_stage);
+        hipLaunchKernelGGL(k_rt, dim3((d.M + 63) / 64, (d.T + RT_TT - 1) / RT_TT, nb), dim3(256), k_rt_lds_bytes(d),
+                           ctx->stream, d, ctx->c, ctx->w, ctx->u_stage, rit_dev);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(R_it + (size_t)s0 * d.T * d.M, rit_dev, sizeof(double) * nb * d.T * d.M,
+                               hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    HIP_TRY(hipFree(rit_dev));
+    ctx->prepared = false;                     // the scan overwrote the prepared-events workspace
     return 0;
 }
 

@@ -152,3 +152,16 @@ class SeirModel:
         L, inv, lf = np.empty_like(x), np.empty_like(x), np.empty_like(x)
         _lib.check(self._lib.seir_selftest_math(self._ctx, x.size, _dptr(x), _dptr(L), _dptr(inv), _dptr(lf)))
         return L, inv, lf
+
+    def reproduction_number(self, theta, events):
+        """R_it [n,T,M] for n posterior draws: column sums of the next-generation matrix
+        (covid19uk/posterior/reproduction_number.py:13-44, model_spec.py:302-368).
+        theta [n,P] constrained draws, events [n,M,T,3]."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        ev = np.ascontiguousarray(events, dtype=np.float64)
+        n = th.shape[0]
+        if th.shape != (n, self.P) or ev.shape != (n, self.M, self.T, 3):
+            raise ValueError(f"need theta [n,{self.P}] and events [n,{self.M},{self.T},3]")
+        out = np.empty((n, self.T, self.M))
+        _lib.check(self._lib.seir_reproduction_number(self._ctx, n, _dptr(th), _dptr(ev), _dptr(out)))
+        return out

@@ -206,6 +206,17 @@ int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, doubl
  * chain state (it only writes its partial-sum buffers). */
 int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms);
 
+/* ------------------------------------------------------------------------
+ * Reproduction number R_it.
+ *
+ * calc_posterior_rit (covid19uk/posterior/reproduction_number.py:13-44): for each
+ * posterior draw and day, the column sums of next_generation_matrix_fn
+ * (covid19uk/model_spec.py:302-368).  theta: n constrained draws [n][P] in the order of
+ * inference.py:541-552; events: [n][M][T][3] fp64 counts (samples/seir); R_it: [n][T][M].
+ * Host pointers, blocking; n is processed in batches of the context's max_chains.
+ * ------------------------------------------------------------------------ */
+int seir_reproduction_number(seir_ctx *ctx, int32_t n, const double *theta, const double *events, double *R_it);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,24 @@ def test_window_bookkeeping():
     assert np.allclose(np.log1p(np.exp(inf.unconstrain_theta(th)[0, :2])) + np.finfo(float).eps, th[0, :2])
     with pytest.raises(KeyError):
         event_kernel_config({"dmax": 1})
+
+
+def test_thin_posterior_matches_reference_slicing(tmp_path):
+    # thin.py:7-21: samples[k][range(start, end, by)] + initial_state, pickled
+    import pickle
+    from covid19uk_amd.posterior.thin import thin_posterior
+    p = str(tmp_path / "posterior.hd5")
+    M, T, m, n = 3, 5, 2, 20
+    post = inf.Posterior(p, M, T, m, n)
+    theta = np.arange(n * (6 + T - 1 + M), dtype=float).reshape(n, 1, -1)
+    events = np.arange(n * M * T * 3).reshape(n, 1, M, T, 3).astype(np.int32)
+    post.write_samples(inf.draws_to_dict(theta, events, 0), 0)
+    post.create_dataset("initial_state", np.ones((M, 4)))
+    post.close()
+    out = thin_posterior(p, str(tmp_path / "thin.pkl"), dict(start=4, end=16, by=3))
+    idx = np.arange(4, 16, 3)
+    assert np.array_equal(out["psi"], theta[idx, 0, 0]) and out["seir"].shape == (4, M, T, 3)
+    assert np.array_equal(out["seir"], events[idx, 0])
+    with open(tmp_path / "thin.pkl", "rb") as f:
+        again = pickle.load(f)
+    assert np.array_equal(again["alpha_t"], theta[idx, 0, 6:6 + T - 1]) and again["initial_state"].shape == (M, 4)
