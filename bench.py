@@ -90,10 +90,18 @@ def main():
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
+    # one process per GPU; RCCL ("nccl") over xGMI.  BENCH_DIST_BACKEND=gloo + BENCH_SHARE_GPU=1
+    # rehearses the N>1 code path with several ranks on ONE GPU (collectives on CPU tensors).
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU") == "1":
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     from covid19uk_amd import distributed as D
     from covid19uk_amd import synth

@@ -193,3 +193,20 @@ def test_device_math_against_mpmath(Model):
         assert abs((mp.mpf(float(inv[i])) - it) / it) < 2e-15, (x[i], inv[i])
         lt = mp.loggamma(mp.floor(xi) + 1)
         assert abs(mp.mpf(float(lf[i])) - lt) <= 2e-15 * max(1, abs(lt)), (x[i], lf[i])
+
+
+def test_syn2048_matches_c_oracle(Model):
+    """BASELINE config 5 shape (2048 regions x 730 days, dense mobility): the K-chunked fp64 MFMA
+    contraction, the multi-chunk scans and the 2048-row reductions against the C oracle."""
+    from oracle import c_binding
+    case = H.build_case("syn2048", 14)
+    c_binding.set_threads(8)
+    u, ev = _batch(case, 2, 14)
+    u[:, :6] = case["u"][:6] + 0.01 * np.random.default_rng(14).normal(size=(2, 6))
+    with Model(case["cov"], case["init"], max_chains=2) as model:
+        lp, g = model.log_prob_grad(u, ev)
+    for b in range(2):
+        want, gw = c_binding.evaluate(case["k"], u[b], ev[b], 1, want_grad=True)
+        assert abs(lp[b] - want) <= RTOL_LOGP * abs(want), (lp[b], want)
+        scale = np.maximum(np.abs(gw), 1e-6 * np.abs(gw).max())
+        assert np.max(np.abs(g[b] - gw) / scale) < RTOL_GRAD
