@@ -171,10 +171,14 @@ def main():
     # HBM-side traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this
     # process): FETCH_SIZE x the gfx950 calibration factor + WRITE_SIZE, same workload and batch.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if a.workload == "uk380" and B == 8 and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["k_se<true,1>"]["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_pmc_summary.json"
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if a.workload == "uk380" and B == 8 and pmcs:
+        doc = json.load(open(pmcs[-1]))
+        ent = doc.get("k_se<true, 1>") or doc.get("k_se<true,1>")
+        if ent:
+            traffic = ent["traffic_bytes_per_launch"]
+            traffic_src = "profiles/" + os.path.basename(pmcs[-1])
 
     # secondary metric: full log_prob evaluations/sec through the stateless C-ABI
     dev = torch.device("cuda", local)

@@ -21,7 +21,7 @@
 namespace seir {
 
 constexpr int SCAN_ROWS = 8;    // rows per k_scan workgroup (2 per wave)
-constexpr int SE_RW = 8;        // k_se: rows per wave; tile = (4*SE_RW) rows x 64 days per workgroup
+constexpr int SE_RW = 4;        // k_se: rows per wave; tile = (4*SE_RW) rows x 64 days per workgroup
 constexpr int SE_TM = 4 * SE_RW;
 constexpr int NSCAL = 16;       // per-chain scalar block
 enum { SC_PSI = 0, SC_SIG, SC_BETA, SC_G0, SC_G1, SC_A0, SC_S0, SC_S1, SC_PRIOR, SC_JAC };

@@ -234,12 +234,12 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             if (t >= 1 && t < T) { qa[k] = q[oT + t]; pa[k] = STAGE == 0 ? 0.0 : p[oT + t]; va[k] = var[oT + t]; }
             const double *kp = w.Kpart + (size_t)b * d.nmt * d.Tp + t;
             double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-            if (d.nmt <= 16) {                           // one batch of loads, no loop-carried waits
-                double v[16];
+            if (d.nmt <= 32) {                           // one batch of loads, no loop-carried waits
+                double v[32];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = j < d.nmt ? kp[(size_t)j * d.Tp] : 0.0;
+                for (int j = 0; j < 32; ++j) v[j] = j < d.nmt ? kp[(size_t)j * d.Tp] : 0.0;
 #pragma unroll
-                for (int j = 0; j < 16; j += 4) { c0 += v[j]; c1 += v[j + 1]; c2 += v[j + 2]; c3 += v[j + 3]; }
+                for (int j = 0; j < 32; j += 4) { c0 += v[j]; c1 += v[j + 1]; c2 += v[j + 2]; c3 += v[j + 3]; }
             } else {
                 for (int ty0 = 0; ty0 < d.nmt; ty0 += 16) {
                     double v[16];

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the round's profile evidence on the GPU box (run from the repo root through gpurun):
+#   bash tools/profile_round.sh r01
+# 1. bench.py under rocprofv3 --kernel-trace --stats (per-kernel durations of the timed region)
+# 2. PMC passes, one counter each and nothing else (FETCH_SIZE, WRITE_SIZE) over a short sampler run
+# 3. the same FETCH_SIZE pass over the load-only probe with known traffic (calibrates gfx950's unit)
+# Raw output goes to gpurun_out/; tools/summarize_profiles.py condenses it into profiles/.
+set -e
+tag=${1:-r01}
+export TMPDIR=/tmp
+out=gpurun_out/${tag}
+rm -rf "$out"; mkdir -p "$out"
+python3 bench.py --steps 200 --warmup 20 > "$out/bench.json" 2> "$out/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o k -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline \
+    > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -o k -- python3 tools/quick_sweep_bench.py --groups 1 --sweeps 20 \
+      > "$out/pmc_$c.log" 2>&1
+done
+if [ -x tools/probes/se_probe ]; then
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_probe" -o k -- tools/probes/se_probe > "$out/pmc_probe.log" 2>&1
+fi
+echo "raw output in $out; now run: python3 tools/summarize_profiles.py $tag $out  (here or after gpurun merged gpurun_out/ back)"

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Condense the raw rocprofv3 output of tools/profile_round.sh into the tracked profiles/ files.
+
+usage: summarize_profiles.py <tag> <raw_dir>
+
+Writes profiles/<tag>_bench.json, _bench_under_rocprof.json, _bench_kernel_stats.csv,
+_pmc_<COUNTER>.csv (mean per kernel) and _pmc_summary.json (HBM traffic per launch of the
+dominant kernel: FETCH_SIZE x calibration + WRITE_SIZE, both reported in KB by rocprofv3).
+
+The calibration factor follows MI355X_MICROARCH.md's HBM section: on gfx950 FETCH_SIZE counts
+64 B for each 128-B request, so the load-only probe with exactly known traffic
+(tools/probes/se_probe.hip, k_var<1,8>: 20 B per cell) is profiled in the same way and its
+known_bytes / reported_bytes ratio (about 2) scales the product kernel's reading.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+DOMINANT = "void seir::k_se<true, 1>"
+PROBE = "void k_var<1, 8>"
+PROBE_BYTES = 8 * 384 * 384 * 20
+
+
+def one(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    return hits[0] if hits else None
+
+
+def counter_means(path):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            a = acc[(row["Kernel_Name"].split("(")[0], row["Counter_Name"])]   # drop the argument list
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    return {k: (s / n, n) for k, (s, n) in acc.items()}
+
+
+def write_means(path, means):
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Counter_Name", "mean", "count"])
+        for (k, c), (m, n) in sorted(means.items()):
+            w.writerow([k, c, m, n])
+
+
+def main():
+    tag, raw = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    for name in ("bench.json", "bench_under_rocprof.json"):
+        src = os.path.join(raw, name)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(prof, f"{tag}_{name}"))
+    stats = one(os.path.join(raw, "stats", "**", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats, os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
+    summary = {"source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
+                         "passes over tools/quick_sweep_bench.py --groups 1 --sweeps 20 (UK-380 x 365, 8 chains)"}
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        p = one(os.path.join(raw, f"pmc_{c}", "**", "*counter_collection.csv"))
+        if not p:
+            continue
+        means = counter_means(p)
+        write_means(os.path.join(prof, f"{tag}_pmc_{c}.csv"), means)
+        if (DOMINANT, c) in means:
+            vals[c] = means[(DOMINANT, c)][0]
+    factor = None
+    p = one(os.path.join(raw, "pmc_probe", "**", "*counter_collection.csv"))
+    if p:
+        means = counter_means(p)
+        write_means(os.path.join(prof, f"{tag}_pmc_probe_FETCH_SIZE.csv"), means)
+        if (PROBE, "FETCH_SIZE") in means:
+            kb = means[(PROBE, "FETCH_SIZE")][0]
+            factor = PROBE_BYTES / (kb * 1024.0)
+            summary["calibration"] = {"kernel": "tools/probes/se_probe.hip k_var<1,8> (loads only, same access widths as k_se)",
+                                      "known_bytes": PROBE_BYTES, "FETCH_SIZE_KB": kb, "factor": factor,
+                                      "note": "gfx950 FETCH_SIZE counts 64 B per 128-B request: factor ~2 "
+                                              "(MI355X_MICROARCH.md, HBM)"}
+    if "FETCH_SIZE" in vals:
+        f = factor if factor else 2.0
+        traffic = vals["FETCH_SIZE"] * 1024.0 * f + vals.get("WRITE_SIZE", 0.0) * 1024.0
+        summary[DOMINANT.replace("void seir::", "")] = {
+            "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals.get("WRITE_SIZE"),
+            "fetch_factor": f, "traffic_bytes_per_launch": traffic}
+    with open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w") as fo:
+        json.dump(summary, fo, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
