@@ -43,6 +43,19 @@ class SeirSamplerDesc(ctypes.Structure):
     ]
 
 
+class SeirSimDesc(ctypes.Structure):
+    """Mirror of `seir_sim_desc` (include/seir_hip.h)."""
+    _fields_ = [
+        ("num_draws", ctypes.c_int32), ("num_steps", ctypes.c_int32),
+        ("first_draw_id", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+        ("par", ctypes.POINTER(ctypes.c_double)), ("log_baseline", ctypes.POINTER(ctypes.c_double)),
+        ("spatial", ctypes.POINTER(ctypes.c_double)), ("W", ctypes.POINTER(ctypes.c_double)),
+        ("weekday_c", ctypes.POINTER(ctypes.c_double)), ("init_state", ctypes.POINTER(ctypes.c_double)),
+        ("events", ctypes.POINTER(ctypes.c_double)),
+    ]
+
+
 MMAX = 4                      # SEIR_MMAX
 MOVE_TRACE = 2 + 4 * MMAX     # SEIR_MOVE_TRACE
 
@@ -76,6 +89,9 @@ _SIGNATURES = {
                                         ctypes.POINTER(ctypes.c_float)]),
     "seir_selftest_math": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [c_double_p] * 4),
     "seir_reproduction_number": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
+    "seir_simulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SeirSimDesc)]),
+    "seir_selftest_binomial": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                              c_double_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int32)]),
     "seir_sampler_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SeirSamplerDesc), c_void_pp]),
     "seir_sampler_destroy": (None, [ctypes.c_void_p]),
     "seir_sampler_set_state": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),

@@ -14,6 +14,7 @@
 
 #include "../../include/seir_hip.h"
 #include "sampler_kernels.h"
+#include "sim_kernels.h"
 #include "moves_kernel.h"
 #include "rt_kernels.h"
 
@@ -478,6 +479,88 @@ extern "C" int seir_reproduction_number(seir_ctx *ctx, int32_t n, const double *
     }
     HIP_TRY(hipFree(rit_dev));
     ctx->prepared = false;                     // the scan overwrote the prepared-events workspace
+    return 0;
+}
+
+// ===========================================================================
+// Forward simulation (see include/seir_hip.h, "Chain-binomial forward simulation")
+// ===========================================================================
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+}  // namespace
+
+extern "C" int seir_simulate(seir_ctx *ctx, const seir_sim_desc *sd) {
+    int rc = check_batch(ctx, 1);
+    if (rc) return rc;
+    if (!sd || sd->num_draws < 1 || sd->num_steps < 1 || !sd->par || !sd->log_baseline || !sd->spatial || !sd->W ||
+        !sd->weekday_c || !sd->init_state || !sd->events)
+        return fail(SEIR_ERR_INVALID, "bad arguments");
+    const Dims &d = ctx->d;
+    const int M = d.M, S = sd->num_steps;
+    if ((long long)S * M > 0x7fffffffLL) return fail(SEIR_ERR_INVALID, "num_steps * M overflows the cell counter");
+    const size_t lds = k_simulate_lds_bytes(d);
+    if (lds > 160 * 1024) return fail(SEIR_ERR_INVALID, "M=%d needs %zu B of LDS for the simulator", M, lds);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // draws per batch: bound the device output buffer to ~512 MB
+    const size_t per_draw = (size_t)M * S * 3 * sizeof(double);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)sd->num_draws, ((size_t)512 << 20) / per_draw));
+    DevBuf par, ap, sp, W, wd, init, ev;
+    if ((rc = par.alloc(sizeof(double) * chunk * 5)) || (rc = ap.alloc(sizeof(double) * chunk * S)) ||
+        (rc = sp.alloc(sizeof(double) * chunk * M)) || (rc = W.alloc(sizeof(double) * S)) ||
+        (rc = wd.alloc(sizeof(double) * S)) || (rc = init.alloc(sizeof(double) * chunk * M * 4)) ||
+        (rc = ev.alloc(per_draw * chunk)))
+        return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(W.p, sd->W, sizeof(double) * S, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(wd.p, sd->weekday_c, sizeof(double) * S, hipMemcpyHostToDevice, st));
+    for (int s0 = 0; s0 < sd->num_draws; s0 += chunk) {
+        const int nb = std::min(chunk, sd->num_draws - s0);
+        HIP_TRY(hipMemcpyAsync(par.p, sd->par + (size_t)s0 * 5, sizeof(double) * nb * 5, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ap.p, sd->log_baseline + (size_t)s0 * S, sizeof(double) * nb * S, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(sp.p, sd->spatial + (size_t)s0 * M, sizeof(double) * nb * M, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(init.p, sd->init_state + (size_t)s0 * M * 4, sizeof(double) * nb * M * 4,
+                               hipMemcpyHostToDevice, st));
+        SimArgs a{};
+        a.n = nb; a.S = S; a.first_draw = sd->first_draw_id + s0;
+        a.k0 = (uint32_t)(sd->seed & 0xffffffffu); a.k1 = (uint32_t)(sd->seed >> 32);
+        a.par = par.as<double>(); a.a_path = ap.as<double>(); a.spatial = sp.as<double>();
+        a.W = W.as<double>(); a.wd = wd.as<double>(); a.init = init.as<double>(); a.events = ev.as<double>();
+        hipLaunchKernelGGL(k_simulate, dim3(nb), dim3(SIM_THREADS), lds, st, d, ctx->c, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sd->events + (size_t)s0 * M * S * 3, ev.p, per_draw * nb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+__global__ void k_selftest_binomial(int count, const int *n, const double *p, uint32_t k0, uint32_t k1, int *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    RngKey key{k0, k1, 0u, (uint32_t)i};
+    out[i] = sim_binomial(n[i], p[i], key, RS_SIM_BASE);
+}
+
+extern "C" int seir_selftest_binomial(seir_ctx *ctx, int32_t count, const int32_t *n, const double *p, uint64_t seed,
+                                      int32_t *out) {
+    int rc = check_batch(ctx, 1);
+    if (rc) return rc;
+    if (count < 1 || !n || !p || !out) return fail(SEIR_ERR_INVALID, "bad arguments");
+    DevBuf dn, dp, dout;
+    if ((rc = dn.alloc(sizeof(int) * count)) || (rc = dp.alloc(sizeof(double) * count)) ||
+        (rc = dout.alloc(sizeof(int) * count)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dn.p, n, sizeof(int) * count, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dp.p, p, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_binomial, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, count, dn.as<int>(),
+                       dp.as<double>(), (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), dout.as<int>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, dout.p, sizeof(int) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

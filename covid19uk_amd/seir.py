@@ -153,6 +153,42 @@ class SeirModel:
         _lib.check(self._lib.seir_selftest_math(self._ctx, x.size, _dptr(x), _dptr(L), _dptr(inv), _dptr(lf)))
         return L, inv, lf
 
+    def simulate(self, par, log_baseline, spatial, W, weekday_c, init_state, seed=0, first_draw_id=0):
+        """Chain-binomial forward simulation of n draws (DiscreteTimeStateTransitionModel.sample as
+        used by covid19uk/posterior/predict.py:50-70): events [n,M,S,3].
+
+        par [n,5] = psi, sigma_space, beta_area, gamma0, gamma1; log_baseline [n,S] = a_t of each
+        simulated day; spatial [n,M]; W, weekday_c [S]; init_state [n,M,4]."""
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        ap = np.ascontiguousarray(log_baseline, dtype=np.float64)
+        sp = np.ascontiguousarray(spatial, dtype=np.float64)
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        wd = np.ascontiguousarray(weekday_c, dtype=np.float64)
+        init = np.ascontiguousarray(init_state, dtype=np.float64)
+        n = par.shape[0]
+        S = ap.shape[1] if ap.ndim == 2 else -1
+        if par.shape != (n, 5) or ap.shape != (n, S) or sp.shape != (n, self.M) or W.shape != (S,) \
+                or wd.shape != (S,) or init.shape != (n, self.M, 4):
+            raise ValueError(f"need par [n,5], log_baseline [n,S], spatial [n,{self.M}], W [S], weekday_c [S], "
+                             f"init_state [n,{self.M},4]")
+        out = np.empty((n, self.M, S, 3))
+        desc = _lib.SeirSimDesc(num_draws=n, num_steps=S, first_draw_id=int(first_draw_id), reserved=0,
+                                seed=int(seed) & 0xFFFFFFFFFFFFFFFF, par=_dptr(par), log_baseline=_dptr(ap),
+                                spatial=_dptr(sp), W=_dptr(W), weekday_c=_dptr(wd), init_state=_dptr(init),
+                                events=_dptr(out))
+        _lib.check(self._lib.seir_simulate(self._ctx, ctypes.byref(desc)))
+        return out
+
+    def selftest_binomial(self, n, p, seed=0):
+        """Device Binomial(n_i, p_i) variates from the simulator's sampler (csrc/sim_kernels.h)."""
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        out = np.empty(n.size, dtype=np.int32)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        _lib.check(self._lib.seir_selftest_binomial(self._ctx, n.size, n.ctypes.data_as(ip), _dptr(p),
+                                                    int(seed) & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(ip)))
+        return out
+
     def reproduction_number(self, theta, events):
         """R_it [n,T,M] for n posterior draws: column sums of the next-generation matrix
         (covid19uk/posterior/reproduction_number.py:13-44, model_spec.py:302-368).

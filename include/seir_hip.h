@@ -217,6 +217,49 @@ int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms
  * ------------------------------------------------------------------------ */
 int seir_reproduction_number(seir_ctx *ctx, int32_t n, const double *theta, const double *events, double *R_it);
 
+/* ------------------------------------------------------------------------
+ * Chain-binomial forward simulation.
+ *
+ * Replaces `CovidUK(covar_data, initial_state=init_, initial_step, num_steps).sample(**par)["seir"]`
+ * mapped over posterior draws in covid19uk/posterior/predict.py:50-70, i.e. gemlib's
+ * DiscreteTimeStateTransitionModel.sample with the rates of covid19uk/model_spec.py:232-276:
+ * day by day, y_x[m] ~ Binomial(source_x[m], 1 - exp(-rate_x[m] time_delta)).
+ *
+ * The caller resolves the model's time indexing on the host (model_spec.py:234-256: W, weekday
+ * and b_t are gathered at clipped absolute day t = initial_step + s) and passes per-day arrays:
+ *   par          [n][5]     psi, sigma_space, beta_area, gamma0, gamma1 (constrained)
+ *   log_baseline [n][S]     a_t of every simulated day
+ *   spatial      [n][M]     spatial_effect
+ *   W, weekday_c [S]        commute volume and centred weekday of every simulated day
+ *   init_state   [n][M][4]  S,E,I,R at the first simulated day (integer-valued)
+ *   events       [n][M][S][3] out, fp64 counts in the reference's layout
+ * Cstar, N, log-area, nu, time_delta and the rate floor come from the context; the context's T
+ * does not limit S.  Random stream: Philox4x32-10 keyed by (seed; attempt, 64 + transition,
+ * s*M + m, first_draw_id + draw) -- independent of batching and of the number of GPUs.
+ * Host pointers, blocking.
+ * ------------------------------------------------------------------------ */
+typedef struct seir_sim_desc {
+    int32_t num_draws;
+    int32_t num_steps;
+    int32_t first_draw_id;
+    int32_t reserved;
+    uint64_t seed;
+    const double *par;
+    const double *log_baseline;
+    const double *spatial;
+    const double *W;
+    const double *weekday_c;
+    const double *init_state;
+    double *events;
+} seir_sim_desc;
+
+int seir_simulate(seir_ctx *ctx, const seir_sim_desc *sim);
+
+/* One Binomial(n, p) variate per element with the simulator's sampler and stream
+ * (cell = element index, transition 0, draw id 0): self-test hook for the distribution tests. */
+int seir_selftest_binomial(seir_ctx *ctx, int32_t count, const int32_t *n, const double *p, uint64_t seed,
+                           int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif
