@@ -89,6 +89,8 @@ _SIGNATURES = {
                                         ctypes.POINTER(ctypes.c_float)]),
     "seir_selftest_math": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [c_double_p] * 4),
     "seir_reproduction_number": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
+    "seir_within_between": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_double,
+                                           c_double_p, c_double_p]),
     "seir_simulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SeirSimDesc)]),
     "seir_selftest_binomial": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                               c_double_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int32)]),

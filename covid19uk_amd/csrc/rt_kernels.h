@@ -99,4 +99,38 @@ __global__ __launch_bounds__(256) void k_rt(Dims d, Consts c, Work w, const doub
 
 inline size_t k_rt_lds_bytes(const Dims &d) { return sizeof(double) * ((size_t)2 * RT_TT * d.Mp + 4 * RT_TT * WAVE); }
 
+// Within-/between-location infection pressure of the last state of every draw
+// (covid19uk/posterior/within_between.py:13-57):
+//   within_m  = I_m - psi (I_m/N_m) W colsum(C)_m        = I_m + psi W Cstar_mm x_m
+//   between_m = psi W ((C + C^T) x)_m                     = psi W ((Cstar x)_m - Cstar_mm x_m)
+// returned as fractions of their sum.  One workgroup per draw, x = I/N in LDS, thread m walks
+// column m of the symmetric Cstar (coalesced across m).
+__global__ __launch_bounds__(256) void k_within_between(Dims d, Consts c, int n, const double *__restrict__ psi,
+                                                         const double *__restrict__ I_last, double W,
+                                                         double *__restrict__ within, double *__restrict__ between) {
+    extern __shared__ double xs[];                       // [Mp]
+    const int b = blockIdx.x;
+    for (int m = threadIdx.x; m < d.Mp; m += 256) xs[m] = m < d.M ? I_last[(size_t)b * d.M + m] * c.invN[m] : 0.0;
+    __syncthreads();
+    const double pw = psi[b] * W;
+    for (int m = threadIdx.x; m < d.M; m += 256) {
+        double F0 = 0.0, F1 = 0.0, F2 = 0.0, F3 = 0.0;
+        const double *col = c.Cstar + m;
+        for (int j = 0; j < d.M; j += 4) {               // xs and Cstar are zero-padded to Mp
+            const double *cj = col + (size_t)j * d.Kp0;
+            // the diagonal (-colsum C) belongs to `within`: leave it out instead of subtracting it back
+            F0 = fma(j == m ? 0.0 : cj[0], xs[j], F0);
+            F1 = fma(j + 1 == m ? 0.0 : cj[d.Kp0], xs[j + 1], F1);
+            F2 = fma(j + 2 == m ? 0.0 : cj[2 * (size_t)d.Kp0], xs[j + 2], F2);
+            F3 = fma(j + 3 == m ? 0.0 : cj[3 * (size_t)d.Kp0], xs[j + 3], F3);
+        }
+        const double self = c.Cstar[(size_t)m * d.Kp0 + m] * xs[m];
+        const double wi = I_last[(size_t)b * d.M + m] + pw * self;
+        const double be = pw * ((F0 + F1) + (F2 + F3));
+        const double tot = wi + be;
+        within[(size_t)b * d.M + m] = wi / tot;
+        between[(size_t)b * d.M + m] = be / tot;
+    }
+}
+
 }  // namespace seir

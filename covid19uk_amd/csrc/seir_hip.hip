@@ -494,6 +494,28 @@ struct DevBuf {
 };
 }  // namespace
 
+extern "C" int seir_within_between(seir_ctx *ctx, int32_t n, const double *psi, const double *I_last, double W,
+                                   double *within, double *between) {
+    int rc = check_batch(ctx, 1);
+    if (rc) return rc;
+    if (n < 1 || !psi || !I_last || !within || !between) return fail(SEIR_ERR_INVALID, "bad arguments");
+    const Dims &d = ctx->d;
+    DevBuf dpsi, dI, dw, db;
+    const size_t nm = sizeof(double) * (size_t)n * d.M;
+    if ((rc = dpsi.alloc(sizeof(double) * n)) || (rc = dI.alloc(nm)) || (rc = dw.alloc(nm)) || (rc = db.alloc(nm)))
+        return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dpsi.p, psi, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dI.p, I_last, nm, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_within_between, dim3(n), dim3(256), sizeof(double) * d.Mp, st, d, ctx->c, n, dpsi.as<double>(),
+                       dI.as<double>(), W, dw.as<double>(), db.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(within, dw.p, nm, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(between, db.p, nm, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
 extern "C" int seir_simulate(seir_ctx *ctx, const seir_sim_desc *sd) {
     int rc = check_batch(ctx, 1);
     if (rc) return rc;

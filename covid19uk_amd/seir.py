@@ -153,6 +153,18 @@ class SeirModel:
         _lib.check(self._lib.seir_selftest_math(self._ctx, x.size, _dptr(x), _dptr(L), _dptr(inv), _dptr(lf)))
         return L, inv, lf
 
+    def within_between(self, psi, I_last, W):
+        """(within, between) fractions [n,M] of the infection pressure of the last state
+        (covid19uk/posterior/within_between.py:13-57).  psi [n], I_last [n,M], W scalar."""
+        psi = np.ascontiguousarray(psi, dtype=np.float64).reshape(-1)
+        I = np.ascontiguousarray(I_last, dtype=np.float64)
+        n = psi.shape[0]
+        if I.shape != (n, self.M):
+            raise ValueError(f"need psi [n] and I_last [n,{self.M}]")
+        wi, be = np.empty((n, self.M)), np.empty((n, self.M))
+        _lib.check(self._lib.seir_within_between(self._ctx, n, _dptr(psi), _dptr(I), float(W), _dptr(wi), _dptr(be)))
+        return wi, be
+
     def simulate(self, par, log_baseline, spatial, W, weekday_c, init_state, seed=0, first_draw_id=0):
         """Chain-binomial forward simulation of n draws (DiscreteTimeStateTransitionModel.sample as
         used by covid19uk/posterior/predict.py:50-70): events [n,M,S,3].

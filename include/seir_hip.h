@@ -217,6 +217,15 @@ int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms
  * ------------------------------------------------------------------------ */
 int seir_reproduction_number(seir_ctx *ctx, int32_t n, const double *theta, const double *events, double *R_it);
 
+/* Within- / between-location infection pressure (second half):
+ * calc_pressure_components (covid19uk/posterior/within_between.py:13-57).  For each draw,
+ * with I the infectives of the last state and x = I/N:
+ *   within  = I - psi x W colsum(C),  between = psi W (C + C^T) x,
+ * returned as fractions within/(within+between), between/(within+between), each [n][M].
+ * psi [n]; I_last [n][M]; W: the commute volume the reference gathers (W[T-1]). Host pointers. */
+int seir_within_between(seir_ctx *ctx, int32_t n, const double *psi, const double *I_last, double W,
+                        double *within, double *between);
+
 /* ------------------------------------------------------------------------
  * Chain-binomial forward simulation.
  *

@@ -47,3 +47,17 @@ def posterior_rit(theta, events, k: so.ModelConstants, stable=False):
             R[s, t] = next_generation_matrix(t, state[:, t, :], par, k, stable).sum(axis=-2)
     weight = k.N / k.N.sum()
     return R, (R * weight[None, None, :]).sum(-1)
+
+
+def pressure_components(psi, state_last, C, N, W_last):
+    """within/between fractions [n,M] -- literal restatement of
+    covid19uk/posterior/within_between.py:13-57 (`C` raw [dest,src], diagonal zeroed there)."""
+    C = np.array(C, dtype=np.float64)
+    np.fill_diagonal(C, 0.0)
+    N = np.asarray(N, dtype=np.float64).reshape(-1)
+    psi = np.asarray(psi, dtype=np.float64).reshape(-1)
+    I = np.asarray(state_last, dtype=np.float64)[..., 2]
+    within = I - psi[:, None] * I / N * W_last * C.sum(axis=-2)
+    between = psi[:, None] * W_last * (I / N) @ (C + C.T).T
+    total = within + between
+    return within / total, between / total

@@ -94,3 +94,62 @@ def test_reproduction_number_stage_end_to_end(tmp_path):
     with hdf5io.File(out, "r") as f:
         assert f.shape("/posterior_predictive/R_it") == (4, T, M)
         assert np.allclose(f.read("/posterior_predictive/R_t"), want_t, rtol=1e-10)
+
+
+def _last_states(case, n, seed):
+    rng = np.random.default_rng(seed)
+    k = case["k"]
+    st = so.compute_state(k.initial_state, case["events"])[:, -1, :]
+    out = np.stack([st] * n)
+    out[:, :, 2] += rng.integers(0, 50, size=(n, k.M))
+    return out
+
+
+def test_pressure_components_match_elementwise_definition():
+    case = H.build_case("micro_3x5", 2)
+    k, cov = case["k"], case["cov"]
+    st = _last_states(case, 2, 1)
+    psi = np.array([0.3, 1.1])
+    wi, be = ro.pressure_components(psi, st, cov.C, cov.N, k.W[-1])
+    C = np.array(cov.C, dtype=np.float64)
+    np.fill_diagonal(C, 0.0)
+    for d in range(2):
+        for m in range(k.M):
+            I = st[d, :, 2]
+            w = I[m] - psi[d] * I[m] / cov.N[m] * k.W[-1] * C[:, m].sum()
+            b = psi[d] * k.W[-1] * sum((C[m, j] + C[j, m]) * I[j] / cov.N[j] for j in range(k.M))
+            assert abs(wi[d, m] - w / (w + b)) < 1e-13 and abs(be[d, m] - b / (w + b)) < 1e-13
+    assert np.allclose(wi + be, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", [("micro_3x5", 2), ("ni11", 4), ("uk380", 3)])
+def test_hip_within_between_matches_oracle(name, n, tmp_path):
+    import pickle
+
+    import __graft_entry__ as entry
+    entry.build()
+    from covid19uk_amd.inference import inference as inf
+    from covid19uk_amd.posterior import within_between as wb
+    case = H.build_case(name, 4)
+    k, cov = case["k"], case["cov"]
+    st = _last_states(case, n, 3)
+    psi = np.linspace(0.2, 0.9, n)
+    want_w, want_b = ro.pressure_components(psi, st, cov.C, cov.N, k.W[-1])
+    got_w, got_b = wb.calc_pressure_components(cov, psi, st, initial_state=case["init"])
+    err = max(np.abs(got_w - want_w).max(), np.abs(got_b - want_b).max())
+    assert err < 1e-12, err                       # fractions in [0,1]: absolute tolerance
+    # file-level entry point
+    data = str(tmp_path / "d.npz")
+    inf.write_inference_data(data, cov, case["events"][:, :, 2])
+    pk = str(tmp_path / "s.pkl")
+    with open(pk, "wb") as f:
+        pickle.dump(dict(psi=psi, seir=np.stack([case["events"]] * n), initial_state=case["init"]), f)
+    w2, b2 = wb.within_between([data, pk], str(tmp_path / "wb.csv"))
+    st2 = np.stack([so.compute_state(case["init"], case["events"])[:, -1, :]] * n)
+    ww, bb = ro.pressure_components(psi, st2, cov.C, cov.N, k.W[-1])
+    # locations without any infection pressure give 0/0 = NaN, in the reference's arithmetic too
+    np.testing.assert_allclose(w2, ww, rtol=0, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(b2, bb, rtol=0, atol=1e-12, equal_nan=True)
+    lines = open(str(tmp_path / "wb.csv")).read().splitlines()
+    assert lines[0].startswith("location,within_mean") and len(lines) == k.M + 1
