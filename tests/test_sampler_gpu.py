@@ -60,6 +60,11 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
     ("micro_5x24", CFG_SMALL, 1, 0.002, 12),
     ("ni11", CFG_REF, 2, 0.002, 8),
     ("micro_17x70", CFG_SMALL, 3, 0.0004, 6),
+    # degenerate and pad-boundary shapes: one LAD, two days, exactly one 64-tile, one past it
+    ("micro_1x6", CFG_SMALL, 4, 0.002, 6),
+    ("micro_2x2", CFG_SMALL, 5, 0.002, 6),
+    ("micro_64x64", CFG_SMALL, 6, 0.0001, 3),
+    ("micro_65x65", CFG_SMALL, 7, 0.0001, 3),
 ])
 def test_fixed_kernel_sweeps_match_oracle(api, monkeypatch, name, cfg, seed, eps, n, moves):
     """Both implementations of the proposal kernel (k_move_pa2 and the first one, k_move_pa)
