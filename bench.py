@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--chains-per-gpu", type=int, default=8)
     ap.add_argument("--adapt-sweeps", type=int, default=60, help="untimed dual-averaging sweeps during setup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chains-scaling", action="store_true",
+                    help="skip the extra (untimed-by-the-contract) runs at 32 and 64 chains on this GPU")
     ap.add_argument("--cpu-baseline-sweeps", type=int, default=0, help="0 = size for ~15 s")
     ap.add_argument("--seed", type=int, default=20210101)
     return ap.parse_args()
@@ -196,6 +198,35 @@ def main():
             model.log_prob_dev(ut, evt, lp, g)
         evals[name] = B * 50 / (model.timer_stop() * 1e-3)
 
+    # context for the headline number (N=1 only, not part of `value`): the same sweep with more
+    # chains resident on this GPU -- at 8 chains the sweep is bound by its dependent-launch chain,
+    # so throughput keeps growing until the gradient kernel saturates HBM
+    scaling = None
+    if world == 1 and not a.no_chains_scaling and a.workload == "uk380":
+        sampler.close()
+        model.close()
+        scaling = {}
+        for Bx in (32, 64):
+            ux = synth.jitter_params(u_true, Bx, scale=0.002, seed=7, T=cov.T)
+            mx = SeirModel(cov, init, max_chains=Bx, device=local)
+            sx = ChainSampler(mx, MCMC_CONFIG, Bx, seed=a.seed, first_chain_id=0, trace_capacity=40,
+                              record_events=True)
+            sx.set_state(ux, np.stack([events] * Bx))
+            sx.set_kernel(step_size=pooled)
+            sx.run(10)
+            mx.sync()
+            sx.reset_trace()
+            mx.timer_start()
+            sx.run(40)
+            msx = mx.timer_stop()
+            gx = sx.time_grad_kernel(100)
+            bytes_x = Bx * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
+            scaling[str(Bx)] = {"samples_per_sec": Bx * 40 / (msx * 1e-3), "ms_per_step": msx / 40,
+                                "grad_kernel_us": 1e3 * gx,
+                                "grad_kernel_frac_of_hbm_peak": bytes_x / (gx * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            sx.close()
+            mx.close()
+
     if rank == 0:
         out = {
             "metric": "posterior samples/sec, 380-LAD UK SEIR" if a.workload == "uk380"
@@ -221,11 +252,14 @@ def main():
             "pcie_inclusive_samples_per_sec": world * B * K / (elapsed + d2h),
             "acceptance": acc, "step_size": pooled, "all_log_probs_finite": finite,
         }
+        if scaling:
+            out["chains_per_gpu_scaling"] = scaling
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed)
         print(json.dumps(out), flush=True)
-    sampler.close()
-    model.close()
+    if scaling is None:
+        sampler.close()
+        model.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
