@@ -32,6 +32,7 @@ struct Dims {
     int b0;                 // first chain handled by this launch (chain groups on separate streams)
     int nrb_scan;           // row blocks of k_scan
     int nmt, ntc;           // k_se tiles: Mp/SE_TM row tiles, Tp/64 day chunks
+    int aff_nb;             // 0 = natural grids (tile, chain); > 0 = 1-D grids of tiles*aff_nb blocks with chain <-> XCD affinity
     double nu, dt, rate_floor, car_half_logdet;
     double L_ei;            // log(1 - exp(-nu dt))
     double prior_const;     // parameter-free part of the summed prior log-densities
@@ -337,15 +338,43 @@ __global__ __launch_bounds__(256) void k_params(Dims d, Consts c, Work w, const 
 // ---------------------------------------------------------------------------
 constexpr int SE_RS = 72;       // LDS row stride (doubles) of the row-sum transpose: conflict-free b64 reads
 
+// Chain <-> XCD affinity (speed only, never correctness): workgroups are dealt round-robin over
+// the 8 XCDs, so blocks L and L+8 share one.  With at most 8 chains in a launch every block of a
+// chain gets an id with the same L % 8, and so do the chain's single-workgroup kernels (block
+// id = chain): partial sums, proposal descriptors and the planes a chain's kernels hand to each
+// other are then found in that XCD's L2 instead of at the cross-XCD rate.
+// Maps the linear block id L of a 1-D grid of per*nb blocks to (chain, tile); the host only sets
+// aff_nb when nb is 1, 2, 4 or 8 and per*nb is a multiple of 8 (otherwise the natural 2-D grid).
+__device__ __forceinline__ void xcd_affine(int L, int per, int nb, int &chain, int &tile) {
+    const int l = L & 7;
+    if (nb == 8) {
+        chain = l;
+        tile = L >> 3;
+    } else {
+        chain = l % nb;
+        tile = (L >> 3) * (8 / nb) + l / nb;
+    }
+}
+inline bool xcd_affinity_applies(int per, int nb) {
+    return (nb == 1 || nb == 2 || nb == 4 || nb == 8) && ((long long)per * nb) % 8 == 0;
+}
+
 template <bool GRAD, int SRC>
 __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     __shared__ double colbuf[4][WAVE];
     __shared__ double llbuf[4][WAVE], psibuf[4][WAVE];
     __shared__ double rowbuf[GRAD ? 4 * SE_RW * SE_RS : 1];
     __shared__ double2 ltab[LOGTAB_N];
-    const int b = d.b0 + blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * WAVE + lane;
-    const int m0 = blockIdx.y * SE_TM + wave * SE_RW;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (d.aff_nb > 0) {
+        int tile;
+        xcd_affine(blockIdx.x, d.ntc * d.nmt, d.aff_nb, bz, tile);
+        bx = tile % d.ntc;
+        by = tile / d.ntc;
+    }
+    const int b = d.b0 + bz, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = bx * WAVE + lane;
+    const int m0 = by * SE_TM + wave * SE_RW;
     if (threadIdx.x < LOGTAB_N) ltab[threadIdx.x] = c.logtab[threadIdx.x];   // barrier below, after the loads
     const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
     const double ea_t = w.ea[(size_t)b * d.Tp + t];
@@ -403,10 +432,10 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
         for (int j = 0; j < SE_RW; j += 2) v += src[j * LPR] + src[(j + 1) * LPR];
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, WAVE);
-        if (ss == 0) w.Rpart[((size_t)b * d.ntc + blockIdx.x) * d.Mp + m0 + rr_] = v;
+        if (ss == 0) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + m0 + rr_] = v;
     }
     __syncthreads();
-    const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)blockIdx.y * d.ntc + blockIdx.x;
+    const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
     if (wave == 0) {
         const double v = wave_sum((llbuf[0][lane] + llbuf[1][lane]) + (llbuf[2][lane] + llbuf[3][lane]));
         if (lane == 0) w.Lpart[tile] = v;
@@ -414,7 +443,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
         const double v = wave_sum((psibuf[0][lane] + psibuf[1][lane]) + (psibuf[2][lane] + psibuf[3][lane]));
         if (lane == 0) w.Ppart[tile] = v;
     } else if (GRAD && wave == 2) {
-        w.Kpart[((size_t)b * d.nmt + blockIdx.y) * d.Tp + t] =
+        w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t] =
             (colbuf[0][lane] + colbuf[1][lane]) + (colbuf[2][lane] + colbuf[3][lane]);
     }
 }

@@ -404,7 +404,9 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
     __shared__ Move pend;
     __shared__ int s_acc;
     __shared__ double s_dth, s_dcn;
-    const int b = d.b0 + blockIdx.y, tid = threadIdx.x;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
+    const int b = d.b0 + by, tid = threadIdx.x;
     const int M = d.M, T = d.T;
     if (have_prev) {
         if (tid == 0) pend = ch.mv[(size_t)pbuf * s.B + b];
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
         if (s_acc && mv.any_dI) {
             // F[j][t] += sum_i Cstar[j][m_i] dI_i / N_{m_i}  on each update's day window
             const int rows_per_blk = (M + s.nrb_d - 1) / s.nrb_d;
-            const int r_lo = blockIdx.x * rows_per_blk, r_hi = min(M, r_lo + rows_per_blk);
+            const int r_lo = bx * rows_per_blk, r_hi = min(M, r_lo + rows_per_blk);
             const int wave = tid >> 6, lane = tid & 63;
             for (int j = r_lo + wave; j < r_hi; j += MVW) {
                 double coef[MMAX];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
                 }
             }
         }
-        if (blockIdx.x == 0) {
+        if (bx == 0) {
             if (s_acc) {
                 for (int i = 0; i < mv.n; ++i) {
                     const size_t rowoff = ((size_t)b * d.Mp + mv.m[i]) * d.Tp;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
             __syncthreads();
         }
     }
-    if (blockIdx.x == 0 && next.kind >= 0) {
+    if (bx == 0 && next.kind >= 0) {
         MvLds L{};
         L.rt = w.rowtot + (size_t)b * 2 * d.Mp;
         L.rstride = d.Mp;

@@ -846,7 +846,9 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
     __shared__ Move mv;
     __shared__ double sh_th[4], sh_cn[4];
     __shared__ double2 ltab[LOGTAB_N];
-    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
+    const int b = d.b0 + by, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) mv = ch.mv[(size_t)buf * s.B + b];
     log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes mv
     double dth = 0.0, dcn = 0.0;
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
         const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
         const double r_ei = d.nu * d.dt, L_ei = d.L_ei;
         const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
-        const int r_lo = blockIdx.x * rows_per_blk, r_hi = min(d.M, r_lo + rows_per_blk);
+        const int r_lo = bx * rows_per_blk, r_hi = min(d.M, r_lo + rows_per_blk);
         const double *ea = w.ea + (size_t)b * d.Tp;
         if (mv.any_dI) {
             for (int j = r_lo + wave; j < r_hi; j += 4) {
@@ -930,7 +932,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
     if (lane == 0) { sh_th[wave] = dth; sh_cn[wave] = dcn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double *out = ch.Dpart + ((size_t)b * s.nrb_d + blockIdx.x) * 2;
+        double *out = ch.Dpart + ((size_t)b * s.nrb_d + bx) * 2;
         out[0] = sh_th[0] + sh_th[1] + sh_th[2] + sh_th[3];
         out[1] = sh_cn[0] + sh_cn[1] + sh_cn[2] + sh_cn[3];
     }

@@ -259,8 +259,14 @@ static int check_batch(seir_ctx *ctx, int B) {
 
 // --- individual launches ---------------------------------------------------
 // `d.b0` selects the first chain, `nb` the number of chains, `st` the stream.
-struct LaunchCfg { Dims d; hipStream_t st; int nb; };
-static LaunchCfg whole(seir_ctx *ctx, int B) { return LaunchCfg{ctx->d, ctx->stream, B}; }
+// `affinity`: give every block of a chain the same (block id % 8), see xcd_affine()
+struct LaunchCfg { Dims d; hipStream_t st; int nb; int affinity; };
+// SEIR_XCD_AFFINITY: bit 0 = gradient kernel, bit 1 = event-move kernels (default 3)
+static int affinity_enabled() {
+    static const int on = getenv("SEIR_XCD_AFFINITY") ? atoi(getenv("SEIR_XCD_AFFINITY")) : 3;
+    return on;
+}
+static LaunchCfg whole(seir_ctx *ctx, int B) { return LaunchCfg{ctx->d, ctx->stream, B, affinity_enabled()}; }
 
 template <int SRC>
 static void launch_scan(seir_ctx *ctx, const LaunchCfg &l, const double *events) {
@@ -281,8 +287,10 @@ static void launch_params(seir_ctx *ctx, const LaunchCfg &l, const double *u) {
 }
 template <int SRC>
 static void launch_se(seir_ctx *ctx, const LaunchCfg &l, bool grad) {
-    const Dims &d = l.d;
-    const dim3 grid(d.ntc, d.nmt, l.nb);
+    Dims d = l.d;
+    const bool affinity = (l.affinity & 1) && xcd_affinity_applies(d.ntc * d.nmt, l.nb);
+    d.aff_nb = affinity ? l.nb : 0;
+    const dim3 grid = affinity ? dim3(d.ntc * d.nmt * l.nb) : dim3(d.ntc, d.nmt, l.nb);
     if (grad)
         hipLaunchKernelGGL((k_se<true, SRC>), grid, dim3(256), 0, l.st, d, ctx->c, ctx->w);
     else
@@ -933,9 +941,8 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     const SamplerCfg &c = s->cfg;
     int b0, nb;
     group_range(s, g, b0, nb);
-    LaunchCfg l{ctx->d, s->gstream[g], nb};
+    LaunchCfg l{ctx->d, s->gstream[g], nb, affinity_enabled()};
     l.d.b0 = b0;
-    const Dims &d = l.d;
     hipStream_t st = l.st;
     // [part 0] HMC on u | events: L+1 gradient evaluations
     launch_se<1>(ctx, l, true);
@@ -948,8 +955,12 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     launch_hmc(ctx, l, c, s->ch, 2);
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
     // per update [finalize previous | propose] then the log-ratio over the touched cells
+    Dims d = l.d;
     {
-        const dim3 gm(c.nrb_d, nb);
+        // the legacy proposal kernel keeps the natural (row block, chain) grid
+        const bool aff = (l.affinity & 2) && !s->legacy_moves && xcd_affinity_applies(c.nrb_d, nb);
+        d.aff_nb = aff ? nb : 0;
+        const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
         int have_prev = 0, pbuf = 0;
         for (int scan = 0; scan < c.n_scans; ++scan)
@@ -973,6 +984,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                 hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
         }
     }
+    d.aff_nb = 0;
     if (s->record_events) hipLaunchKernelGGL(k_record, dim3(32, nb), dim3(256), 0, st, d, ctx->w, c, s->ch);
     hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);
 }
