@@ -134,8 +134,10 @@ constexpr int HWV = HB / WAVE;      // waves
 constexpr int NRED = 8;
 #ifdef SEIR_STAMPS
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) ((unsigned long long *)(hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_DRAIN(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); STAMP(i); } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMP_DRAIN(i) do {} while (0)
 #endif
 
 // standard normal for component i of the momentum (Box-Muller; components 2j, 2j+1 share a Philox call)
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     __shared__ double red[HWV * NRED];
     __shared__ double scn[HWV];
     __shared__ double bc[12];                          // broadcast scalars
+    __shared__ double bc2[2];
     __shared__ int s_accept;
     __shared__ double2 ltab[LOGTAB_N];
     const int b = d.b0 + blockIdx.x, tid = threadIdx.x;
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     const int ntile = d.nmt * d.ntc;
     double lpart = 0.0, ppart = 0.0;
     for (int i = tid; i < ntile; i += HB) { lpart += w.Lpart[(size_t)b * ntile + i]; ppart += w.Ppart[(size_t)b * ntile + i]; }
+    STAMP_DRAIN(10);
 #pragma unroll
     for (int k = 0; k < HT; ++k) {
         const int t = tid + k * HB;
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             col[k] = (c0 + c1) + (c2 + c3);
         }
     }
+    STAMP_DRAIN(11);
 #pragma unroll
     for (int k = 0; k < HM; ++k) {
         const int m = tid + k * HB;
@@ -273,11 +278,27 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             Rm[k] = (r0 + r1) + (r2 + r3);
         }
     }
+    // constants of phase 3 (CAR precision rows in ELL form): fetched now, used after the leapfrog
+    constexpr int QPRE = 8;
+    double qell_v[HM][QPRE];
+    int qell_c[HM][QPRE];
+    const bool ell_pre = c.qw > 0 && c.qw <= QPRE;
+#pragma unroll
+    for (int k = 0; k < HM; ++k) {
+        const int m = tid + k * HB;
+#pragma unroll
+        for (int j = 0; j < QPRE; ++j) {
+            const bool on = ell_pre && m < M && j < c.qw;
+            qell_v[k][j] = on ? c.Qell_val[(size_t)j * d.Mp + m] : 0.0;
+            qell_c[k][j] = on ? c.Qell_col[(size_t)j * d.Mp + m] : 0;
+        }
+    }
     double q6[6], p6[6], v6[6];
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { q6[i] = q[i]; p6[i] = STAGE == 0 ? 0.0 : p[i]; v6[i] = var[i]; }
     }
+    STAMP_DRAIN(12);
     lds_barrier();                                     // ltab
     STAMP(1);
 
@@ -486,12 +507,24 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { q[i] = q6[i]; if (STAGE != 2) p[i] = p6[i]; }
-        const double e0 = 2.220446049250313e-16;
-        bc[0] = softplus(q6[0]) + e0; bc[1] = softplus(q6[1]) + e0;
         bc[2] = q6[2]; bc[3] = q6[3]; bc[4] = q6[4]; bc[5] = q6[5];
         bc[6] = q6[0]; bc[7] = q6[1];
     }
-    lds_barrier();                                     // bc, lds_sp (LDS only: do not drain the stores)
+    lds_barrier();                                     // bc[6..7], lds_sp (LDS only: do not drain the stores)
+    // the two softplus and what follows from them (log psi for the Gamma prior, the sigmoids of the
+    // chain rule) are ~3 serial libm calls each: lane 0 of waves 0 and 1 take one parameter each
+    if ((tid & 63) == 0 && (tid >> 6) < 2) {
+        const int i = tid >> 6;
+        const double e0 = 2.220446049250313e-16;
+        const double u = bc[6 + i];
+        const double sp = softplus(u);
+        bc[i] = sp + e0;
+        const double ls = u - sp;                      // log sigmoid(u) = u - softplus(u)
+        bc[8 + i] = ls;
+        bc[10 + i] = cold_exp(ls);
+        if (i == 0) bc2[0] = cold_log(sp + e0);
+    }
+    lds_barrier();
     STAMP(6);
 
     // ---------------- phase 3: tables and priors at the new position -----------
@@ -519,7 +552,10 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         if (m < M) {
             w.eb[(size_t)b * d.Mp + m] = exp(nbeta * lam[k] + nsig * qm[k]) * inN[k];
             double acc = 0.0;
-            if (c.qw > 0) {
+            if (ell_pre) {
+#pragma unroll
+                for (int j = 0; j < QPRE; ++j) acc += qell_v[k][j] * lds_sp[qell_c[k][j]];
+            } else if (c.qw > 0) {
                 for (int e0 = 0; e0 < c.qw; e0 += 8) {
                     double qv[8]; int qc[8];
 #pragma unroll
@@ -545,18 +581,16 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         // model_spec.py:140-198; the parameter-free normalisers are folded into d.prior_const
         double lp = d.prior_const;
         lp += -0.5 * na0 * na0 / 100.0 - 0.5 * nbeta * nbeta;
-        lp += 2.0 * cold_log(npsi) - 10.0 * npsi;
+        lp += 2.0 * bc2[0] - 10.0 * npsi;
         lp += -0.5 * pr[0] / (0.005 * 0.005);
         lp += -nsig * nsig / 0.02;
         lp += -0.5 * pr[1];
         lp += -0.5 * (ng0 * ng0 + ng1 * ng1) / 1.0e4;
         sc[SC_PSI] = npsi; sc[SC_SIG] = nsig; sc[SC_BETA] = nbeta; sc[SC_G0] = ng0; sc[SC_G1] = ng1;
         sc[SC_A0] = na0;
-        // log sigmoid(u) = u - softplus(u)
-        const double ls0 = bc[6] - (npsi - 2.220446049250313e-16), ls1 = bc[7] - (nsig - 2.220446049250313e-16);
-        sc[SC_S0] = cold_exp(ls0); sc[SC_S1] = cold_exp(ls1);
+        sc[SC_S0] = bc[10]; sc[SC_S1] = bc[11];
         sc[SC_PRIOR] = lp;
-        sc[SC_JAC] = ls0 + ls1;
+        sc[SC_JAC] = bc[8] + bc[9];
     }
     STAMP(9);
     if (STAGE == 2) {

@@ -23,8 +23,10 @@ with SeirModel(cov, init, max_chains=B) as model:
         lib.seir_sampler_debug_hs(s._s, hs.ctypes.data_as(_lib.c_double_p))
         st = hs[0, 16:32].view(np.uint64)
         if cfg["num_event_time_updates"] == 0:
-            st = st[:10].astype(np.int64)
-            print("stamps (10ns ticks) deltas:", np.diff(st) * 10, "ns ; total", (st[-1] - st[0]) * 10, "ns")
+            st = st.astype(np.int64)
+            print("stamps (10ns ticks) deltas:", np.diff(st[:10]) * 10, "ns ; total", (st[9] - st[0]) * 10, "ns")
+            print("phase 0 split: kernarg+scalars+L/Ppart", (st[10] - st[0]) * 10, "Kpart+T vectors", (st[11] - st[10]) * 10,
+                  "Rpart+M vectors", (st[12] - st[11]) * 10, "barrier", (st[1] - st[12]) * 10, "ns")
         else:
             names = ["mvSE", "mvEI", "ocSE", "ocEI"]
             for i, v in enumerate(st):
