@@ -263,8 +263,8 @@ static int check_batch(seir_ctx *ctx, int B) {
 struct LaunchCfg { Dims d; hipStream_t st; int nb; int affinity; };
 // SEIR_XCD_AFFINITY: bit 0 = gradient kernel, bit 1 = event-move kernels (default 3)
 static int affinity_enabled() {
-    static const int on = getenv("SEIR_XCD_AFFINITY") ? atoi(getenv("SEIR_XCD_AFFINITY")) : 3;
-    return on;
+    const char *e = getenv("SEIR_XCD_AFFINITY");     // read per call: launches are enqueued at graph capture
+    return e ? atoi(e) : 3;
 }
 static LaunchCfg whole(seir_ctx *ctx, int B) { return LaunchCfg{ctx->d, ctx->stream, B, affinity_enabled()}; }
 

@@ -192,6 +192,36 @@ def test_chains_are_independent_of_batch_composition(api):
     assert np.array_equal(tr_all.hmc["target_log_prob"][:, 2], tr_one.hmc["target_log_prob"][:, 0])
 
 
+@pytest.mark.parametrize("B,groups,affinity", [(8, 1, "3"), (8, 1, "0"), (3, 1, "3"), (16, 1, "3"), (8, 2, "3"), (6, 4, "3")])
+def test_launch_geometries_give_identical_chains(api, monkeypatch, B, groups, affinity):
+    """Block-to-chain mappings (XCD affinity for 1/2/4/8 chains per launch, natural grids
+    otherwise, chain groups on separate streams) only move work around: every chain's trace must
+    be bit-identical to the same chain run alone."""
+    monkeypatch.setenv("SEIR_CHAIN_GROUPS", str(groups))
+    monkeypatch.setenv("SEIR_XCD_AFFINITY", affinity)
+    SeirModel, ChainSampler = api
+    case = H.build_case("micro_17x70", 9, alpha_t_sd=0.005)
+    u, ev = _start(case, B, 9)
+    n = 4
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, CFG_SMALL, B, seed=5, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.0004)
+            tr_all = s.sample(n)
+    monkeypatch.setenv("SEIR_CHAIN_GROUPS", "1")
+    for b in (0, B - 1):
+        with SeirModel(case["cov"], case["init"], max_chains=1) as model:
+            with ChainSampler(model, CFG_SMALL, 1, seed=5, first_chain_id=b, trace_capacity=n) as s:
+                s.set_state(u[b:b + 1], ev[b:b + 1])
+                s.set_kernel(step_size=0.0004)
+                tr_one = s.sample(n)
+        assert np.array_equal(tr_all.theta[:, b], tr_one.theta[:, 0]), b
+        assert np.array_equal(tr_all.events[:, b], tr_one.events[:, 0]), b
+        for key in tr_all.moves:
+            assert np.array_equal(tr_all.moves[key]["proposed_delta"][:, b], tr_one.moves[key]["proposed_delta"][:, 0])
+    assert tr_all.hmc["is_accepted"].any()
+
+
 def test_sampler_argument_errors(api):
     from covid19uk_amd import _lib
     SeirModel, ChainSampler = api
