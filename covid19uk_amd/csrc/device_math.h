@@ -40,6 +40,8 @@ __device__ __forceinline__ double lbinom(double n, double k) {
 // The table lives in LDS (filled from Consts.logtab by log_table_to_lds).
 // ---------------------------------------------------------------------------
 constexpr int LOGTAB_N = 128;
+// LDS copy of the math tables: the log table followed by log(n!) for n < LFACT_TABLE packed two per entry
+constexpr int LDSTAB_N = LOGTAB_N + LFACT_TABLE / 2;
 __device__ __forceinline__ double fast_log(double x, const double2 *tab) {
     const long long bits = __double_as_longlong(x);
     const int k = (int)((bits >> 52) & 0x7ff) - 1023;
@@ -58,19 +60,6 @@ __device__ __forceinline__ double fast_log(double x, const double2 *tab) {
     return fma(kd, 0.69314718055994529, tc.y) + fma(kd, 2.3190468138462996e-17, p);
 }
 
-// Stirling with the table log (the hot kernels' form of lfact / lbinom)
-__device__ __forceinline__ double lfact(double n, const double2 *tab) {
-    if (n < (double)LFACT_TABLE) return c_lfact[(int)n];
-    const double x = n + 1.0;
-    const double xi = 1.0 / x, xi2 = xi * xi;
-    const double corr = xi * (8.333333333333333e-2 - xi2 * (2.777777777777778e-3 - xi2 * (7.936507936507937e-4 - xi2 * 5.952380952380952e-4)));
-    return (x - 0.5) * fast_log(x, tab) - x + 0.9189385332046727 + corr;
-}
-__device__ __forceinline__ double lbinom(double n, double k, const double2 *tab) {
-    if (k < 0.0 || k > n) return -INFINITY;
-    return lfact(n, tab) - lfact(k, tab) - lfact(n - k, tab);
-}
-
 // reciprocal of a positive normal double: v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -79,8 +68,23 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// Stirling with the table log (the hot kernels' form of lfact / lbinom)
+__device__ __forceinline__ double lfact(double n, const double2 *tab) {
+    // small n from the LDS copy: a divergent read of the __constant__ table is a global load
+    if (n < (double)LFACT_TABLE) return reinterpret_cast<const double *>(tab + LOGTAB_N)[(int)n];
+    const double x = n + 1.0;
+    const double xi = fast_rcp(x), xi2 = xi * xi;   // the correction is < 1.3e-3: 1 ulp of 1/x is far below fp64 here
+    const double corr = xi * (8.333333333333333e-2 - xi2 * (2.777777777777778e-3 - xi2 * (7.936507936507937e-4 - xi2 * 5.952380952380952e-4)));
+    return (x - 0.5) * fast_log(x, tab) - x + 0.9189385332046727 + corr;
+}
+__device__ __forceinline__ double lbinom(double n, double k, const double2 *tab) {
+    if (k < 0.0 || k > n) return -INFINITY;
+    return lfact(n, tab) - lfact(k, tab) - lfact(n - k, tab);
+}
+
+
 __device__ __forceinline__ void log_table_to_lds(double2 *lds_tab, const double2 *__restrict__ gtab) {
-    if (threadIdx.x < LOGTAB_N) lds_tab[threadIdx.x] = gtab[threadIdx.x];
+    if (threadIdx.x < LDSTAB_N) lds_tab[threadIdx.x] = gtab[threadIdx.x];
     __syncthreads();
 }
 
@@ -167,24 +171,48 @@ __device__ __forceinline__ double wave_min(double v) {
 }
 
 // inclusive prefix sum across the 64 lanes of a wave
+// DPP moves for the scans: a lane whose source is outside its 16-lane row, or whose row is
+// masked off, receives 0 (old = 0, bound_ctrl off).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_get0(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get0(double v) {
+    return dpp_mov0<CTRL, ROW_MASK, 0xf>(v);
+}
+__device__ __forceinline__ int lane_value(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_value(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave: Hillis-Steele inside each row of 16 with
+// row_shr 1,2,4,8, then the row totals with row_bcast 15 (into rows 1,3) and row_bcast 31 (into
+// rows 2,3) -- six register-to-register steps instead of six ds_bpermute round trips per word.
 template <typename T>
 __device__ __forceinline__ T wave_incl_scan(T v, int lane) {
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        T n = __shfl_up(v, o, WAVE);
-        if (lane >= o) v += n;
-    }
+    (void)lane;
+    v += dpp_get0<0x111, 0xf>(v);
+    v += dpp_get0<0x112, 0xf>(v);
+    v += dpp_get0<0x114, 0xf>(v);
+    v += dpp_get0<0x118, 0xf>(v);
+    v += dpp_get0<0x142, 0xa>(v);
+    v += dpp_get0<0x143, 0xc>(v);
     return v;
 }
 
-// inclusive suffix sum across the 64 lanes of a wave (lane l gets sum_{j>=l})
+// Inclusive suffix sum across the 64 lanes of a wave (lane l gets sum_{j>=l}): row_shl 1,2,4,8
+// inside each row, then the totals of the rows behind (lane 0 of each row) through readlane.
 __device__ __forceinline__ double wave_incl_suffix_scan(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const double n = __shfl_down(v, o, WAVE);
-        if (lane + o < WAVE) v += n;
-    }
-    return v;
+    v += dpp_get0<0x101, 0xf>(v);
+    v += dpp_get0<0x102, 0xf>(v);
+    v += dpp_get0<0x104, 0xf>(v);
+    v += dpp_get0<0x108, 0xf>(v);
+    const double t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48);
+    const int row = lane >> 4;
+    const double behind = row == 0 ? (t1 + t2) + t3 : row == 1 ? t2 + t3 : row == 2 ? t3 : 0.0;
+    return v + behind;
 }
 
 // Exclusive prefix sum over a 256-thread block (thread order); `sh` needs 4

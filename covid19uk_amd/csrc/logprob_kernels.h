@@ -20,7 +20,9 @@
 
 namespace seir {
 
-constexpr int SCAN_ROWS = 8;    // rows per k_scan workgroup (2 per wave)
+constexpr int SCAN_ROWS = 8;    // rows per k_scan workgroup
+constexpr int SCAN_WAVES = 8;   // one row per wave: 3 waves per SIMD at UK-380 x 8 chains, evenly
+constexpr int SCAN_CB = 6;      // k_scan: 64-day chunks fetched per batch (6 = one batch at T <= 384)
 constexpr int SE_RW = 4;        // k_se: rows per wave; tile = (4*SE_RW) rows x 64 days per workgroup
 constexpr int SE_TM = 4 * SE_RW;
 constexpr int NSCAL = 16;       // per-chain scalar block
@@ -45,7 +47,7 @@ struct Consts {
     const double *init;            // [Mp][4]
     const int *Qrow, *Qcol;        // CSR of car_Q
     const double *Qval;
-    const double2 *logtab;         // [LOGTAB_N] (1/c, log c) of device_math.h fast_log
+    const double2 *logtab;         // [LDSTAB_N] (1/c, log c) of device_math.h fast_log, then log(n!) pairs
     int qw;                        // ELL width of car_Q (0: use the CSR arrays)
     const int *Qell_col;           // [qw][Mp]
     const double *Qell_val;        // [qw][Mp]
@@ -77,9 +79,9 @@ struct Work {
 // SRC 1: events from the sampler's int32 planes; writes St planes, Xn, rowtot.
 // ---------------------------------------------------------------------------
 template <int SRC>
-__global__ __launch_bounds__(256) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
-    extern __shared__ double lds[];                 // [4][Tp][2]
-    __shared__ double2 ltab[LOGTAB_N];
+__global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
+    extern __shared__ double lds[];                 // [SCAN_WAVES][Tp][2]
+    __shared__ double2 ltab[LDSTAB_N];
     const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *mycol = lds + (size_t)wave * d.Tp * 2;
     for (int i = lane; i < d.Tp * 2; i += WAVE) mycol[i] = 0.0;
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(256) void k_scan(Dims d, Consts c, Work w, const do
     const double r_ei = d.nu * d.dt;
     const double L_ei = d.L_ei;
     const int nch = d.Tp / WAVE;
-    constexpr int RPW = SCAN_ROWS / 4;
+    constexpr int RPW = SCAN_ROWS / SCAN_WAVES;
+    constexpr int CB = SCAN_CB;                      // day chunks loaded per batch, before any arithmetic
     for (int r = 0; r < RPW; ++r) {
         const int m = blockIdx.x * SCAN_ROWS + wave * RPW + r;
         if (m >= d.M) break;
@@ -97,42 +100,55 @@ __global__ __launch_bounds__(256) void k_scan(Dims d, Consts c, Work w, const do
         const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
         const double *ev = SRC == 0 ? events + ((size_t)b * d.M + m) * d.T * 3 : nullptr;
         double cse = 0.0, cei = 0.0, cir = 0.0, rc = 0.0;
-        for (int ch = 0; ch < nch; ++ch) {
-            const int t = ch * WAVE + lane;
-            const bool valid = t < d.T;
-            double kse = 0.0, kei = 0.0, kir = 0.0;
-            if (SRC == 0) {
-                if (valid) {
-                    kse = ev[(size_t)t * 3 + 0];
-                    kei = ev[(size_t)t * 3 + 1];
-                    kir = ev[(size_t)t * 3 + 2];
+        for (int ch0 = 0; ch0 < nch; ch0 += CB) {
+            // all loads of the batch first: the chunks are independent up to the carried prefix,
+            // so nothing below waits on memory more than once per batch
+            double kse[CB], kei[CB], kir[CB];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int t = (ch0 + j) * WAVE + lane;
+                kse[j] = kei[j] = kir[j] = 0.0;
+                if (ch0 + j < nch) {
+                    if (SRC == 0) {
+                        if (t < d.T) {
+                            kse[j] = ev[(size_t)t * 3 + 0];
+                            kei[j] = ev[(size_t)t * 3 + 1];
+                            kir[j] = ev[(size_t)t * 3 + 2];
+                        }
+                    } else {
+                        kse[j] = (double)w.K[0][rowoff + t];
+                        kei[j] = (double)w.K[1][rowoff + t];
+                        kir[j] = (double)w.K[2][rowoff + t];
+                    }
                 }
-            } else {
-                kse = (double)w.K[0][rowoff + t];
-                kei = (double)w.K[1][rowoff + t];
-                kir = (double)w.K[2][rowoff + t];
             }
-            const double ise = wave_incl_scan(kse, lane), iei = wave_incl_scan(kei, lane),
-                         iir = wave_incl_scan(kir, lane);
-            const double xse = cse + ise - kse, xei = cei + iei - kei, xir = cir + iir - kir;
-            const double S = S0 - xse, E = E0 + xse - xei, I = I0 + xei - xir;
-            w.Xn[rowoff + t] = valid ? I * invN : 0.0;
-            if (SRC == 0) {
-                w.KS[rowoff + t] = valid ? make_int2((int)kse, (int)(S - kse)) : make_int2(0, 0);
-            } else {
-                w.St[0][rowoff + t] = valid ? (int)S : 0;
-                w.St[1][rowoff + t] = valid ? (int)E : 0;
-                w.St[2][rowoff + t] = valid ? (int)I : 0;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                if (ch0 + j >= nch) break;
+                const int t = (ch0 + j) * WAVE + lane;
+                const bool valid = t < d.T;
+                const double ise = wave_incl_scan(kse[j], lane), iei = wave_incl_scan(kei[j], lane),
+                             iir = wave_incl_scan(kir[j], lane);
+                const double xse = cse + ise - kse[j], xei = cei + iei - kei[j], xir = cir + iir - kir[j];
+                const double S = S0 - xse, E = E0 + xse - xei, I = I0 + xei - xir;
+                w.Xn[rowoff + t] = valid ? I * invN : 0.0;
+                if (SRC == 0) {
+                    w.KS[rowoff + t] = valid ? make_int2((int)kse[j], (int)(S - kse[j])) : make_int2(0, 0);
+                } else {
+                    w.St[0][rowoff + t] = valid ? (int)S : 0;
+                    w.St[1][rowoff + t] = valid ? (int)E : 0;
+                    w.St[2][rowoff + t] = valid ? (int)I : 0;
+                }
+                if (valid) {
+                    rc += lbinom(S, kse[j], ltab) + lbinom(E, kei[j], ltab) + lbinom(I, kir[j], ltab);
+                    rc += kei[j] * L_ei - (E - kei[j]) * r_ei;
+                    mycol[t * 2 + 0] += kir[j];
+                    mycol[t * 2 + 1] += I - kir[j];
+                }
+                cse += __shfl(ise, WAVE - 1, WAVE);
+                cei += __shfl(iei, WAVE - 1, WAVE);
+                cir += __shfl(iir, WAVE - 1, WAVE);
             }
-            if (valid) {
-                rc += lbinom(S, kse, ltab) + lbinom(E, kei, ltab) + lbinom(I, kir, ltab);
-                rc += kei * L_ei - (E - kei) * r_ei;
-                mycol[t * 2 + 0] += kir;
-                mycol[t * 2 + 1] += I - kir;
-            }
-            cse += __shfl(ise, WAVE - 1, WAVE);
-            cei += __shfl(iei, WAVE - 1, WAVE);
-            cir += __shfl(iir, WAVE - 1, WAVE);
         }
         rc = wave_sum(rc);
         if (lane == 0) {
@@ -146,32 +162,47 @@ __global__ __launch_bounds__(256) void k_scan(Dims d, Consts c, Work w, const do
     __syncthreads();
     double *out = w.colIR + ((size_t)b * d.nrb_scan + blockIdx.x) * d.Tp * 2;
     const int n = d.Tp * 2;
-    for (int i = threadIdx.x; i < n; i += 256) out[i] = lds[i] + lds[n + i] + lds[2 * n + i] + lds[3 * n + i];
+    for (int i = threadIdx.x; i < n; i += SCAN_WAVES * WAVE) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < SCAN_WAVES; ++k) a += lds[k * n + i];
+        out[i] = a;
+    }
 }
 
-// One workgroup per chain: Kir_t, Dir_t (integer-valued, exact in any order) and
-// the sum of the row constants.
+// Grid (Tp/64, chains): Kir_t, Dir_t of 64 days per workgroup (integer-valued, exact in any
+// order); block 0 of a chain also sums the row constants.
 __global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) {
     __shared__ double sh[4];
-    const int b = d.b0 + blockIdx.x;
-    for (int t = threadIdx.x; t < d.Tp; t += 256) {
-        double a = 0.0, e = 0.0, a1 = 0.0, e1 = 0.0;
-        const double2 *p = (const double2 *)w.colIR + (size_t)b * d.nrb_scan * d.Tp + t;
-        int rb = 0;
-        for (; rb + 3 < d.nrb_scan; rb += 4) {          // integer-valued sums: any order is exact
-            const double2 v0 = p[(size_t)rb * d.Tp], v1 = p[(size_t)(rb + 1) * d.Tp];
-            const double2 v2 = p[(size_t)(rb + 2) * d.Tp], v3 = p[(size_t)(rb + 3) * d.Tp];
-            a += v0.x + v2.x; e += v0.y + v2.y; a1 += v1.x + v3.x; e1 += v1.y + v3.y;
+    __shared__ double2 part[4][WAVE];
+    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * WAVE + lane;
+    // wave w folds the partial rows rb = w, w+4, ...; 16 loads in flight per batch
+    double a = 0.0, e = 0.0;
+    const double2 *p = (const double2 *)w.colIR + (size_t)b * d.nrb_scan * d.Tp + t;
+    for (int rb0 = wave; rb0 < d.nrb_scan; rb0 += 64) {
+        double2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int rb = rb0 + 4 * j;
+            v[j] = rb < d.nrb_scan ? p[(size_t)rb * d.Tp] : make_double2(0.0, 0.0);
         }
-        for (; rb < d.nrb_scan; ++rb) { const double2 v = p[(size_t)rb * d.Tp]; a += v.x; e += v.y; }
-        a += a1; e += e1;
-        w.Kir[(size_t)b * d.Tp + t] = a;
-        w.Dir[(size_t)b * d.Tp + t] = e;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { a += v[j].x; e += v[j].y; }      // integer-valued sums: any order is exact
     }
-    double acc = 0.0;
-    for (int m = threadIdx.x; m < d.M; m += 256) acc += w.rowconst[(size_t)b * d.Mp + m];
-    acc = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) w.constsum[b] = acc;
+    part[wave][lane] = make_double2(a, e);
+    __syncthreads();
+    if (wave == 0) {
+        const double2 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+        w.Kir[(size_t)b * d.Tp + t] = (p0.x + p1.x) + (p2.x + p3.x);
+        w.Dir[(size_t)b * d.Tp + t] = (p0.y + p1.y) + (p2.y + p3.y);
+    }
+    if (blockIdx.x == 0) {
+        double acc = 0.0;
+        for (int m = threadIdx.x; m < d.M; m += 256) acc += w.rowconst[(size_t)b * d.Mp + m];
+        acc = block_sum_256(acc, sh);
+        if (threadIdx.x == 0) w.constsum[b] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -364,7 +395,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     __shared__ double colbuf[4][WAVE];
     __shared__ double llbuf[4][WAVE], psibuf[4][WAVE];
     __shared__ double rowbuf[GRAD ? 4 * SE_RW * SE_RS : 1];
-    __shared__ double2 ltab[LOGTAB_N];
+    __shared__ double2 ltab[LDSTAB_N];
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (d.aff_nb > 0) {
         int tile;
@@ -548,7 +579,7 @@ __global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const 
     extern __shared__ double lds_col[];             // [Tp]
     __shared__ double sh[4];
     __shared__ double seg[256];
-    __shared__ double2 ltab[LOGTAB_N];
+    __shared__ double2 ltab[LDSTAB_N];
     const int b = d.b0 + blockIdx.x;
     log_table_to_lds(ltab, c.logtab);
     const double lp = reduce_chain<GRAD>(d, c, w, b, u_all + (size_t)b * d.P,

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     __shared__ double bc[12];                          // broadcast scalars
     __shared__ double bc2[2];
     __shared__ int s_accept;
-    __shared__ double2 ltab[LOGTAB_N];
+    __shared__ double2 ltab[LDSTAB_N];
     const int b = d.b0 + blockIdx.x, tid = threadIdx.x;
     const int T = d.T, M = d.M;
     double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp, *q0 = ch.q0 + (size_t)b * d.Pp;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void k_chain_refresh(Dims d, Consts c, Work w,
     extern __shared__ double lds_col[];
     __shared__ double sh[4];
     __shared__ double seg[256];
-    __shared__ double2 ltab[LOGTAB_N];
+    __shared__ double2 ltab[LDSTAB_N];
     const int b = d.b0 + blockIdx.x;
     log_table_to_lds(ltab, c.logtab);
     const double lik = reduce_chain<false>(d, c, w, b, ch.q + (size_t)b * d.Pp, nullptr, lds_col, seg, sh, ltab);
@@ -879,7 +879,7 @@ __device__ inline void cell_terms(const Dims &d, double S, double E, double I, d
 __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf) {
     __shared__ Move mv;
     __shared__ double sh_th[4], sh_cn[4];
-    __shared__ double2 ltab[LOGTAB_N];
+    __shared__ double2 ltab[LDSTAB_N];
     int bx = blockIdx.x, by = blockIdx.y;
     if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
     const int b = d.b0 + by, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

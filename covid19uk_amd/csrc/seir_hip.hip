@@ -162,7 +162,11 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
     }
     if (qcol.empty()) { qcol.push_back(0); qval.push_back(0.0); }
     // table of device_math.h fast_log: c_i = 1 + (i + 1/2)/128, (fl(1/c_i), -log(fl(1/c_i)))
-    std::vector<double2> ltab(LOGTAB_N);
+    std::vector<double2> ltab(LDSTAB_N);
+    for (int i = 0; i < LFACT_TABLE / 2; ++i) {
+        ltab[LOGTAB_N + i].x = lf[2 * i];
+        ltab[LOGTAB_N + i].y = lf[2 * i + 1];
+    }
     for (int i = 0; i < LOGTAB_N; ++i) {
         const long double cc = 1.0L + ((long double)i + 0.5L) / (long double)LOGTAB_N;
         const double invc = (double)(1.0L / cc);
@@ -271,11 +275,14 @@ static LaunchCfg whole(seir_ctx *ctx, int B) { return LaunchCfg{ctx->d, ctx->str
 template <int SRC>
 static void launch_scan(seir_ctx *ctx, const LaunchCfg &l, const double *events) {
     const Dims &d = l.d;
-    hipLaunchKernelGGL(k_scan<SRC>, dim3(d.nrb_scan, l.nb), dim3(256), (size_t)4 * d.Tp * 2 * sizeof(double),
+    const size_t lds = (size_t)SCAN_WAVES * d.Tp * 2 * sizeof(double);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_scan<SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_scan<SRC>, dim3(d.nrb_scan, l.nb), dim3(SCAN_WAVES * WAVE), lds,
                        l.st, d, ctx->c, ctx->w, events);
 }
 static void launch_colreduce(seir_ctx *ctx, const LaunchCfg &l) {
-    hipLaunchKernelGGL(k_colreduce, dim3(l.nb), dim3(256), 0, l.st, l.d, ctx->w);
+    hipLaunchKernelGGL(k_colreduce, dim3(l.d.Tp / WAVE, l.nb), dim3(256), 0, l.st, l.d, ctx->w);
 }
 static void launch_gemm(seir_ctx *ctx, const LaunchCfg &l) {
     const Dims &d = l.d;
@@ -435,7 +442,7 @@ extern "C" int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t
 }
 
 __global__ void k_selftest_math(Consts c, int n, const double *x, double *L, double *inv, double *lf) {
-    __shared__ double2 ltab[LOGTAB_N];
+    __shared__ double2 ltab[LDSTAB_N];
     log_table_to_lds(ltab, c.logtab);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         double a, b2;
