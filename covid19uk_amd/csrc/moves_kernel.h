@@ -397,6 +397,7 @@ __device__ __forceinline__ void range_totals_to_lds(const Dims &d, const Work &w
 // by block 0 -- then (2) block 0 draws the next proposal.  next.kind < 0: finalize only.
 // grid (nrb_d, B), MVB threads.  The pending descriptor is read from buffer pbuf, the next one
 // written to pbuf^1 (late blocks must not see the new one).
+// next.kind == -2: finalize only and advance the chain's sweep counter (closing launch of a sweep).
 __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
                                                   int have_prev, int pbuf) {
     extern __shared__ int dyn_i[];                     // block 0: rg [M] | rk, rsrc, rdst [MMAX][T+1]
@@ -479,6 +480,8 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
             __syncthreads();
         }
     }
+    // nothing in this launch reads the counter after block 0's trace write above
+    if (bx == 0 && next.kind == -2 && tid == 0) ch.sweep[b] += 1;
     if (bx == 0 && next.kind >= 0) {
         MvLds L{};
         L.rt = w.rowtot + (size_t)b * 2 * d.Mp;

@@ -1059,20 +1059,30 @@ __global__ __launch_bounds__(256) void k_move_pa(Dims d, Consts c, Work w, Sampl
     if (blockIdx.x == 0 && next.kind >= 0) propose(d, w, s, ch, b, next, pbuf ^ 1, cnt_sh, ish);
 }
 
-// End of sweep: record the event tensor in the reference's [M][T][3] order and
-// advance the sweep counter.  grid (blocks, B).
-__global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Chains ch) {
-    const int b = d.b0 + blockIdx.y;
-    const unsigned slot = ch.sweep[b] - ch.slot0[0];
-    if (slot < (unsigned)s.cap) {
-        int *out = ch.tr_events + ((size_t)slot * s.B + b) * d.M * d.T * 3;
-        const size_t n = (size_t)d.M * d.T;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-            const int t = (int)(i % d.T), m = (int)(i / d.T);
-            const size_t q = ((size_t)b * d.Mp + m) * d.Tp + t;
-            out[i * 3 + 0] = w.K[0][q];
-            out[i * 3 + 1] = w.K[1][q];
-            out[i * 3 + 2] = w.K[2][q];
+// End of sweep: record the event tensor in the reference's [M][T][3] order.  One wave per row,
+// lanes over days (coalesced plane reads, no index division); grid (ceil(M/4), B).
+// `advanced`: the sweep counter was already incremented by the closing k_move_pa2.
+__global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Chains ch, int advanced) {
+    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    const unsigned slot = ch.sweep[b] - (unsigned)advanced - ch.slot0[0];
+    if (slot >= (unsigned)s.cap || m >= d.M) return;
+    int *out = ch.tr_events + (((size_t)slot * s.B + b) * d.M + m) * d.T * 3;
+    const size_t q0 = ((size_t)b * d.Mp + m) * d.Tp;
+    for (int t0 = 0; t0 < d.T; t0 += 4 * WAVE) {
+        int k0[4], k1[4], k2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                     // pads exist up to Tp: unconditional loads
+            const int t = t0 + j * WAVE + lane;
+            const bool in = t < d.Tp;
+            k0[j] = in ? w.K[0][q0 + t] : 0;
+            k1[j] = in ? w.K[1][q0 + t] : 0;
+            k2[j] = in ? w.K[2][q0 + t] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j * WAVE + lane;
+            if (t < d.T) { out[t * 3 + 0] = k0[j]; out[t * 3 + 1] = k1[j]; out[t * 3 + 2] = k2[j]; }
         }
     }
 }

@@ -963,6 +963,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
     // per update [finalize previous | propose] then the log-ratio over the touched cells
     Dims d = l.d;
+    int advanced = 0;
     {
         // the legacy proposal kernel keeps the natural (row block, chain) grid
         const bool aff = (l.affinity & 2) && !s->legacy_moves && xcd_affinity_applies(c.nrb_d, nb);
@@ -984,16 +985,21 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                 have_prev = 1;
             }
         if (have_prev) {
-            const MoveSpec none{-1, 0, 0, 0};
-            if (s->legacy_moves)
+            // closing launch: finalize the last proposal; k_move_pa2 also advances the sweep counter
+            if (s->legacy_moves) {
+                const MoveSpec none{-1, 0, 0, 0};
                 hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
-            else
+            } else {
+                const MoveSpec none{-2, 0, 0, 0};
                 hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+                advanced = 1;
+            }
         }
     }
     d.aff_nb = 0;
-    if (s->record_events) hipLaunchKernelGGL(k_record, dim3(32, nb), dim3(256), 0, st, d, ctx->w, c, s->ch);
-    hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);
+    if (s->record_events)
+        hipLaunchKernelGGL(k_record, dim3((d.M + 3) / 4, nb), dim3(256), 0, st, d, ctx->w, c, s->ch, advanced);
+    if (!advanced) hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);
 }
 
 extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
