@@ -18,6 +18,15 @@
 
 namespace seir {
 
+#ifdef SEIR_STAMPS
+#ifndef SEIR_STAMP_SLOT
+#define SEIR_STAMP_SLOT 1
+#endif
+#define MSTAMP(i) do { if (threadIdx.x == 0 && stamp_on) ((unsigned long long *)(stamp_hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MSTAMP(i) do {} while (0)
+#endif
+
 constexpr int MVB = 512;              // threads
 constexpr int MVW = MVB / WAVE;       // waves
 constexpr int MVU = 4;                // cells in flight per thread in the band loops
@@ -47,12 +56,26 @@ __device__ __forceinline__ int mv_excl_scan(int v, int *sh, int &total) {
     return base + inc - v;
 }
 
+// min over the 64 lanes (result uniform): row_shr 1,2,4,8, row_bcast 15/31; min is idempotent, so
+// the overlapping Hillis-Steele windows are harmless.  Lanes without a source receive INT_MAX.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_step(int v) {
+    return min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_min_int(int v) {
+    v = dpp_min_step<0x111, 0xf>(v);
+    v = dpp_min_step<0x112, 0xf>(v);
+    v = dpp_min_step<0x114, 0xf>(v);
+    v = dpp_min_step<0x118, 0xf>(v);
+    v = dpp_min_step<0x142, 0xa>(v);
+    v = dpp_min_step<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 template <int NV>
 __device__ __forceinline__ void mv_minv(int (&v)[NV], int *sh) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[k] = min(v[k], __shfl_xor(v[k], o, WAVE));
+    for (int k = 0; k < NV; ++k) v[k] = wave_min_int(v[k]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     lds_barrier();
     if (lane == 0) {
@@ -83,10 +106,13 @@ __device__ __forceinline__ void mv_sum2(double &a, double &b2, double *sh) {
 
 // arrays the proposal works from
 struct MvLds {
-    const int *rt;         // [2][rstride] row totals of S->E / E->I events (global)
-    int rstride;
+    const int *rt;         // [M] row totals of the target transition's events (LDS copy, patched)
+    int rstride;           // unused (kept for the layout of the first implementation)
     int *rg;               // [M] events of the target transition inside the occult range (LDS)
     int *rk, *rsrc, *rdst; // [MMAX][T+1] staged rows (LDS): target events, compartments either side at start of day
+#ifdef SEIR_STAMPS
+    double *stamp_hs; bool stamp_on;
+#endif
 };
 
 // Change of the S->E term of a cell whose F moves by dF while its own state is unchanged:
@@ -120,29 +146,45 @@ __device__ __forceinline__ double band_delta(double S, double I, double K0, doub
     return out;
 }
 
-__device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
-                                  MoveSpec spec, MvShared &sm, const MvLds &L) {
+// log of a small positive integer-valued double (counts, bounds): table log; log 1 = 0 exactly
+__device__ __forceinline__ double mv_log(double x, const double2 *ltab) { return x == 1.0 ? 0.0 : fast_log(x, ltab); }
+
+// Uniforms and descriptor header of a proposal: they depend on (seed, chain, sweep, scan, slot)
+// only, so the kernel draws them at entry, overlapped with its first round of loads; the first
+// barrier after this call publishes them.
+__device__ inline void mv_draw(const SamplerCfg &s, const Chains &ch, int b, MoveSpec spec, MvShared &sm, int T) {
     Move &mv = sm.mv;
-    const int tid = threadIdx.x, M = d.M, T = d.T, T1 = T + 1;
+    const int tid = threadIdx.x;
+    if (tid >= 2 * MMAX && tid != 64) return;
     const RngKey key = rng_key(s, ch, b);
     const uint32_t stream = RS_MOVE_BASE + (uint32_t)(spec.scan * 4 + spec.slot);
-    const int tgt = spec.tgt;
-    // uniforms: one lane per draw slot (slot 15 = the accept uniform), broadcast through LDS
+    // one lane per draw slot (slot 15 = the accept uniform), broadcast through LDS
     if (tid < 2 * MMAX) rng_uniform2(key, stream, (uint32_t)tid, sm.u[tid][0], sm.u[tid][1]);
     if (tid == 64) {
-        mv.valid = 1; mv.n = 0; mv.tgt = tgt; mv.kind = spec.kind; mv.slot = spec.slot;
+        mv.valid = 1; mv.n = 0; mv.tgt = spec.tgt; mv.kind = spec.kind; mv.slot = spec.slot;
         mv.logq = 0.0; mv.any_dI = 0; mv.LO = T; mv.HI = -1;
         for (int j = 0; j < MMAX; ++j) { mv.tm[j] = mv.tt[j] = mv.tdt[j] = mv.tx[j] = 0; mv.b[j] = -1; sm.pend_valid[j] = -1; }
         double ua, ub;
         rng_uniform2(key, stream, 15u, ua, ub);
         mv.logu = cold_log(ua);
     }
+}
+
+__device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
+                                  MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab) {
+    Move &mv = sm.mv;
+    const int tid = threadIdx.x, M = d.M, T = d.T, T1 = T + 1;
+#ifdef SEIR_STAMPS
+    double *stamp_hs = L.stamp_hs; const bool stamp_on = L.stamp_on;
+#endif
+    MSTAMP(4);
+    const int tgt = spec.tgt;
     const int per = (M + MVB - 1) / MVB;
     const int r_lo = tid * per, r_hi = min(M, r_lo + per);
 
     if (spec.kind == 0) {
         // ---- UncalibratedEventTimesUpdate ---------------------------------
-        const int *rt = L.rt + tgt * L.rstride;
+        const int *rt = L.rt;
         int c = 0;
         for (int m = r_lo; m < r_hi; ++m) c += rt[m] > 0 ? 1 : 0;
         int H;
@@ -169,6 +211,7 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
                     }
             }
         lds_barrier();
+        MSTAMP(5);
         // stage the chosen rows: k[t], source and destination compartments at the start of day t in [0,T]
         for (int idx = tid; idx < nsel * T1; idx += MVB) {
             const int j = idx / T1, t = idx - j * T1;
@@ -178,6 +221,7 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
             L.rdst[idx] = comp_start(d, w, rowoff, tgt + 1, t);
         }
         __syncthreads();
+        MSTAMP(6);
         // day of each row: the floor(u D)-th day with events
         const int tper = (T + MVB - 1) / MVB;
         const int t_lo = tid * tper, t_hi = min(T, t_lo + tper);
@@ -200,6 +244,7 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
             Dj[j] = D;
         }
         lds_barrier();
+        MSTAMP(7);
         // bounds: min over (lo,hi] of the compartment that loses x, and of the one that gains it
         int mins[2 * MMAX];
         int mj[MMAX], dj[MMAX], t2j[MMAX];
@@ -221,6 +266,7 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
             }
         }
         mv_minv<2 * MMAX>(mins, sm.ired);
+        MSTAMP(8);
         // one lane per metapopulation finishes its update
         const int jj = tid >> 6;
         if ((tid & 63) == 0 && jj < nsel) {
@@ -242,8 +288,8 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
                 const int Dn = D - ((x > 0 && x == kt) ? 1 : 0) + ((x > 0 && kt2 == 0) ? 1 : 0);
                 const long long binc = inc_unbounded ? 0x7fffffffLL : (long long)min_inc + x;
                 const int xmax_r = (int)max(0LL, min((long long)min(s.nmax, kt2 + x), binc));
-                sm.logq_part[j] = (-cold_log((double)Dn) - cold_log((double)(xmax_r + 1))) -
-                                  (-cold_log((double)D) - cold_log((double)(xmax + 1)));
+                sm.logq_part[j] = (-mv_log((double)Dn, ltab) - mv_log((double)(xmax_r + 1), ltab)) -
+                                  (-mv_log((double)D, ltab) - mv_log((double)(xmax + 1), ltab));
                 sm.pend_valid[j] = 1;
                 mv.m[j] = m; mv.a[j] = t; mv.b[j] = t2; mv.dka[j] = -x; mv.dkb[j] = x;
                 mv.lo[j] = min(t, t2); mv.hi[j] = max(t, t2);
@@ -252,6 +298,7 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
             }
         }
         lds_barrier();
+        MSTAMP(9);
         if (tid == 0) {
             // compact the in-range updates (order preserved) and combine the correction
             int n = 0;
@@ -294,6 +341,7 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
             }
         }
         lds_barrier();
+        MSTAMP(5);
         const int m = sm.sel[0];
         const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
         for (int t = tid; t < T1; t += MVB) {
@@ -302,6 +350,7 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
             L.rdst[t] = comp_start(d, w, rowoff, tgt + 1, t);
         }
         __syncthreads();
+        MSTAMP(6);
         // hot days of row m inside the range; the day of a delete is the floor(u Dm)-th of them
         int cc = 0;
         const int rper = (R + MVB - 1) / MVB;
@@ -323,36 +372,38 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
             sm.sel[1] = s.tr_lo + rng_index(u_t, R);
         }
         lds_barrier();
+        MSTAMP(7);
         const int t = sm.sel[1];
         int mins[2] = {0x7fffffff, 0x7fffffff};
         for (int tau = t + 1 + tid; tau <= T; tau += MVB) { mins[0] = min(mins[0], L.rsrc[tau]); mins[1] = min(mins[1], L.rdst[tau]); }
         mv_minv<2>(mins, sm.ired);
+        MSTAMP(8);
         if (tid == 0) {
             const int min_src = tgt == 0 ? 0x7fffffff : mins[0], min_dst = mins[1];
             const int kt = L.rk[t], rt_m = rg[m];
-            const double lM = cold_log((double)M), lR = cold_log((double)R), l2 = 0.6931471805599453;
+            const double lM = mv_log((double)M, ltab), lR = mv_log((double)R, ltab), l2 = 0.6931471805599453;
             int x;
             if (!is_del) {
                 const int xmax = max(0, min(s.occult_nmax, min_src));
                 x = rng_index(u_x, xmax + 1);
-                const double qf = (Hd > 0 ? -l2 : 0.0) - lM - lR - cold_log((double)(xmax + 1));
+                const double qf = (Hd > 0 ? -l2 : 0.0) - lM - lR - mv_log((double)(xmax + 1), ltab);
                 const int Hd2 = Hd + ((rt_m == 0 && x > 0) ? 1 : 0);
                 const int Dm2 = Dm + ((kt == 0 && x > 0) ? 1 : 0);
                 const long long bd = (long long)min_dst + x;
                 const int xmax_r = (int)max(0LL, min((long long)min(s.occult_nmax, kt + x), bd));
                 const double qr = (Hd2 > 0 && kt + x > 0)
-                                      ? -l2 - cold_log((double)Hd2) - cold_log((double)Dm2) - cold_log((double)(xmax_r + 1))
+                                      ? -l2 - mv_log((double)Hd2, ltab) - mv_log((double)Dm2, ltab) - mv_log((double)(xmax_r + 1), ltab)
                                       : -INFINITY;
                 mv.logq = qr - qf;
                 mv.dka[0] = x; mv.dsrc[0] = -x;
             } else {
                 const int xmax = max(0, min(min(s.occult_nmax, kt), min_dst));
                 x = rng_index(u_x, xmax + 1);
-                const double qf = -l2 - cold_log((double)Hd) - cold_log((double)Dm) - cold_log((double)(xmax + 1));
+                const double qf = -l2 - mv_log((double)Hd, ltab) - mv_log((double)Dm, ltab) - mv_log((double)(xmax + 1), ltab);
                 const int Hd2 = Hd - ((x > 0 && rt_m == x) ? 1 : 0);
                 const long long bs = tgt == 0 ? 0x7fffffffLL : (long long)min_src + x;
                 const int xmax_r = (int)max(0LL, min((long long)s.occult_nmax, bs));
-                const double qr = (Hd2 > 0 ? -l2 : 0.0) - lM - lR - cold_log((double)(xmax_r + 1));
+                const double qr = (Hd2 > 0 ? -l2 : 0.0) - lM - lR - mv_log((double)(xmax_r + 1), ltab);
                 mv.logq = qr - qf;
                 mv.dka[0] = -x; mv.dsrc[0] = x;
             }
@@ -400,15 +451,62 @@ __device__ __forceinline__ void range_totals_to_lds(const Dims &d, const Work &w
 // next.kind == -2: finalize only and advance the chain's sweep counter (closing launch of a sweep).
 __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
                                                   int have_prev, int pbuf) {
-    extern __shared__ int dyn_i[];                     // block 0: rg [M] | rk, rsrc, rdst [MMAX][T+1]
+    extern __shared__ int dyn_i[];                     // block 0: rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm;
     __shared__ Move pend;
+    __shared__ double2 ltab[LOGTAB_N];
     __shared__ int s_acc;
     __shared__ double s_dth, s_dcn;
     int bx = blockIdx.x, by = blockIdx.y;
     if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
     const int b = d.b0 + by, tid = threadIdx.x;
     const int M = d.M, T = d.T;
+    // ---- everything block 0 will need that does not depend on the accept decision is fetched
+    // now, in the same round trip as the pending descriptor and the partial sums; what the
+    // pending update changes (row totals, range totals) is patched after the decision.
+    const bool proposer = bx == 0 && next.kind >= 0;
+#ifdef SEIR_STAMPS
+    double *stamp_hs = ch.hs + (size_t)b * NHS;
+    const bool stamp_on = proposer && b == 0 && next.slot == SEIR_STAMP_SLOT && next.scan == 0;
+#endif
+    MSTAMP(0);
+    constexpr int PRE_RT = 4;                                  // rows per thread (M <= 2048)
+    const int R = s.tr_hi - s.tr_lo;
+    const bool pre_rt = proposer && M <= PRE_RT * MVB;
+    // kind 0: the row totals of the target plane; kind 1: each row's events inside the occult range
+    int rt_pre[PRE_RT];
+#pragma unroll
+    for (int k = 0; k < PRE_RT; ++k) {
+        const int m = tid + k * MVB;
+        rt_pre[k] = 0;
+        if (pre_rt && m < M) {
+            if (next.kind == 0) {
+                rt_pre[k] = w.rowtot[((size_t)b * 2 + next.tgt) * d.Mp + m];
+            } else {
+                const int *kr = w.K[next.tgt] + ((size_t)b * d.Mp + m) * d.Tp + s.tr_lo;
+                int acc = 0;
+                for (int t0 = 0; t0 < R; t0 += 8) {
+                    int v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = t0 + j < R ? kr[t0 + j] : 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += v[j];
+                }
+                rt_pre[k] = acc;
+            }
+        }
+    }
+    if (proposer) {
+        if (tid >= 128 && tid < 128 + LOGTAB_N) ltab[tid - 128] = c.logtab[tid - 128];
+        mv_draw(s, ch, b, next, sm, T);
+    }
+    double hs_th = 0.0, hs_cn = 0.0;
+    unsigned tr_slot = 0xffffffffu;
+    if (bx == 0 && have_prev && tid == 0) {
+        const double *hs = ch.hs + (size_t)b * NHS;
+        hs_th = hs[HS_LP_THETA]; hs_cn = hs[HS_LP_CONST];
+        tr_slot = ch.sweep[b] - ch.slot0[0];
+    }
     if (have_prev) {
         if (tid == 0) pend = ch.mv[(size_t)pbuf * s.B + b];
         double dth = 0.0, dcn = 0.0;
@@ -417,6 +515,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
             dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
         }
         mv_sum2(dth, dcn, sm.dred);
+        MSTAMP(1);
         if (tid == 0) {
             const double ratio = dth + dcn + pend.logq;
             s_acc = (pend.valid && pend.logu < ratio) ? 1 : 0;   // NaN -> reject
@@ -465,39 +564,84 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
             }
             if (tid == 0) {
                 double *hs = ch.hs + (size_t)b * NHS;
-                if (s_acc) { hs[HS_LP_THETA] += s_dth; hs[HS_LP_CONST] += s_dcn; }
-                const unsigned slot = ch.sweep[b] - ch.slot0[0];
-                if (slot < (unsigned)s.cap) {
-                    double *tr = ch.tr_mv + (((size_t)slot * s.B + b) * 4 + mv.slot) * NMVTR;
+                if (s_acc) {
+                    hs_th += s_dth; hs_cn += s_dcn;
+                    hs[HS_LP_THETA] = hs_th; hs[HS_LP_CONST] = hs_cn;
+                }
+                if (tr_slot < (unsigned)s.cap) {
+                    double *tr = ch.tr_mv + (((size_t)tr_slot * s.B + b) * 4 + mv.slot) * NMVTR;
                     tr[0] = (double)s_acc;
-                    tr[1] = hs[HS_LP_THETA] + hs[HS_LP_CONST];
+                    tr[1] = hs_th + hs_cn;
                     for (int j = 0; j < MMAX; ++j) {
                         tr[2 + j] = mv.tm[j]; tr[2 + MMAX + j] = mv.tt[j];
                         tr[2 + 2 * MMAX + j] = mv.tdt[j]; tr[2 + 3 * MMAX + j] = mv.tx[j];
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();               // LDS only: tid 0's trace stores need not drain before the proposal
         }
     }
+    MSTAMP(2);
     // nothing in this launch reads the counter after block 0's trace write above
     if (bx == 0 && next.kind == -2 && tid == 0) ch.sweep[b] += 1;
-    if (bx == 0 && next.kind >= 0) {
+    if (proposer) {
         MvLds L{};
-        L.rt = w.rowtot + (size_t)b * 2 * d.Mp;
-        L.rstride = d.Mp;
+        int *rtl = dyn_i + M;
+        L.rt = rtl;
+        L.rstride = 0;
         L.rg = dyn_i;
-        L.rk = dyn_i + M;
+        L.rk = dyn_i + 2 * M;
         L.rsrc = L.rk + MMAX * (T + 1);
         L.rdst = L.rsrc + MMAX * (T + 1);
-        if (next.kind == 1) range_totals_to_lds(d, w, s, b, next.tgt, L.rg);
-        mv_propose(d, w, s, ch, b, next, sm, L);
+        const bool patch = have_prev && s_acc && pend.tgt == next.tgt;
+        if (next.kind == 0) {
+            // row totals of the target plane: prefetched values (+ what the accepted update moved)
+            if (pre_rt) {
+#pragma unroll
+                for (int k = 0; k < PRE_RT; ++k) {
+                    const int m = tid + k * MVB;
+                    if (m < M) rtl[m] = rt_pre[k];
+                }
+                lds_barrier();
+                if (patch && tid == 0)
+                    for (int i = 0; i < pend.n; ++i) rtl[pend.m[i]] += pend.dka[i] + pend.dkb[i];
+            } else {
+                __syncthreads();                              // block 0's own row-total stores above
+                for (int m = tid; m < M; m += MVB) rtl[m] = w.rowtot[((size_t)b * 2 + next.tgt) * d.Mp + m];
+            }
+            lds_barrier();
+        } else {
+            if (pre_rt) {
+#pragma unroll
+                for (int k = 0; k < PRE_RT; ++k) {
+                    const int m = tid + k * MVB;
+                    if (m < M) L.rg[m] = rt_pre[k];
+                }
+                lds_barrier();
+                if (patch && tid == 0)
+                    for (int i = 0; i < pend.n; ++i) {
+                        if (pend.a[i] >= s.tr_lo && pend.a[i] < s.tr_hi) L.rg[pend.m[i]] += pend.dka[i];
+                        if (pend.b[i] >= s.tr_lo && pend.b[i] < s.tr_hi) L.rg[pend.m[i]] += pend.dkb[i];
+                    }
+                lds_barrier();
+            } else {
+                __syncthreads();                              // block 0's own K stores above
+                range_totals_to_lds(d, w, s, b, next.tgt, L.rg);
+            }
+        }
+        MSTAMP(3);
+#ifdef SEIR_STAMPS
+        L.stamp_hs = stamp_hs; L.stamp_on = stamp_on;
+#endif
+        mv_propose(d, w, s, ch, b, next, sm, L, ltab);
+        MSTAMP(10);
         if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm.mv;
+        MSTAMP(11);
     }
 }
 
 inline size_t k_move_pa2_lds_bytes(const Dims &d) {
-    return sizeof(int) * ((size_t)d.M + 3 * MMAX * (d.T + 1));
+    return sizeof(int) * ((size_t)2 * d.M + 3 * MMAX * (d.T + 1));
 }
 
 }  // namespace seir

@@ -1,7 +1,7 @@
 import ctypes, os, sys, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from covid19uk_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libseirhip_stamps.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libseirhip_stamps" + os.environ.get("STAMP_SLOT", "") + ".so")
 from covid19uk_amd import synth
 from covid19uk_amd.sampler import ChainSampler
 from covid19uk_amd.seir import SeirModel
@@ -28,7 +28,13 @@ with SeirModel(cov, init, max_chains=B) as model:
             print("phase 0 split: kernarg+scalars+L/Ppart", (st[10] - st[0]) * 10, "Kpart+T vectors", (st[11] - st[10]) * 10,
                   "Rpart+M vectors", (st[12] - st[11]) * 10, "barrier", (st[1] - st[12]) * 10, "ns")
         else:
-            names = ["mvSE", "mvEI", "ocSE", "ocEI"]
+            st = st.astype(np.int64)
+            print("k_move_pa2 block 0, slot", os.environ.get("STAMP_SLOT", "1"), ": entry->sums", (st[1]-st[0])*10, "finalize", (st[2]-st[1])*10,
+                  "tables", (st[3]-st[2])*10, "propose: rng/init", (st[4]-st[3])*10, "select rows", (st[5]-st[4])*10,
+                  "stage rows", (st[6]-st[5])*10, "select days", (st[7]-st[6])*10, "mins", (st[8]-st[7])*10,
+                  "finish lanes", (st[9]-st[8])*10, "compact", (st[10]-st[9])*10, "store", (st[11]-st[10])*10,
+                  "ns ; total", (st[11]-st[0])*10)
+            names = []
             for i, v in enumerate(st):
                 v = int(v)
                 print(f"scan {i // 4} {names[i % 4]}: propose {(v & 0xfffff) / 100:.2f} us, delta {((v >> 20) & 0xfffff) / 100:.2f} us, "
