@@ -213,12 +213,28 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
         lds_barrier();
         MSTAMP(5);
         // stage the chosen rows: k[t], source and destination compartments at the start of day t in [0,T]
-        for (int idx = tid; idx < nsel * T1; idx += MVB) {
-            const int j = idx / T1, t = idx - j * T1;
-            const size_t rowoff = ((size_t)b * d.Mp + sm.sel[j]) * d.Tp;
-            L.rk[idx] = t < T ? w.K[tgt][rowoff + t] : 0;
-            L.rsrc[idx] = comp_start(d, w, rowoff, tgt, t);
-            L.rdst[idx] = comp_start(d, w, rowoff, tgt + 1, t);
+        {
+            constexpr int NST = 4;                                // elements per thread per batch
+            for (int base = tid; base < nsel * T1; base += MVB * NST) {
+                int vk[NST], vs[NST], vd[NST];
+#pragma unroll
+                for (int q = 0; q < NST; ++q) {
+                    const int idx = base + q * MVB;
+                    vk[q] = vs[q] = vd[q] = 0;
+                    if (idx < nsel * T1) {
+                        const int j = idx / T1, t = idx - j * T1;
+                        const size_t rowoff = ((size_t)b * d.Mp + sm.sel[j]) * d.Tp;
+                        vk[q] = t < T ? w.K[tgt][rowoff + t] : 0;
+                        vs[q] = comp_start(d, w, rowoff, tgt, t);
+                        vd[q] = comp_start(d, w, rowoff, tgt + 1, t);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NST; ++q) {
+                    const int idx = base + q * MVB;
+                    if (idx < nsel * T1) { L.rk[idx] = vk[q]; L.rsrc[idx] = vs[q]; L.rdst[idx] = vd[q]; }
+                }
+            }
         }
         __syncthreads();
         MSTAMP(6);
@@ -485,12 +501,12 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
             } else {
                 const int *kr = w.K[next.tgt] + ((size_t)b * d.Mp + m) * d.Tp + s.tr_lo;
                 int acc = 0;
-                for (int t0 = 0; t0 < R; t0 += 8) {
-                    int v[8];
+                for (int t0 = 0; t0 < R; t0 += 32) {           // one batch at the reference's 21-day range
+                    int v[32];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = t0 + j < R ? kr[t0 + j] : 0;
+                    for (int j = 0; j < 32; ++j) v[j] = t0 + j < R ? kr[t0 + j] : 0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc += v[j];
+                    for (int j = 0; j < 32; ++j) acc += v[j];
                 }
                 rt_pre[k] = acc;
             }
