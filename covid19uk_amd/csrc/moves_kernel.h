@@ -115,37 +115,6 @@ struct MvLds {
 #endif
 };
 
-// Change of the S->E term of a cell whose F moves by dF while its own state is unchanged:
-//   k [L(r1) - L(r0)] - (S-k)(r1 - r0),  L(r) = log(1-exp(-r)),  r1 = r0 + a.
-// In the small-rate regime L(r1)-L(r0) = log(r1/r0) + g(r1) - g(r0) with log(r1/r0) = 2 atanh(z),
-// z = a/(2 r0 + a): one reciprocal and two short polynomials instead of two table logs, and more
-// accurate than differencing them.
-__device__ __forceinline__ double band_delta(double S, double I, double K0, double F, double dF, double ee,
-                                             double psiW, double floor_dt, double dt, const double2 *ltab) {
-    const double r0 = ee * (I + psiW * F) * dt + floor_dt;
-    const double a = ee * psiW * dF * dt;
-    const double r1 = r0 + a;
-    double out = -(S - K0) * a;
-    if (K0 != 0.0) {
-        const double z = a * fast_rcp(r0 + r1);
-        double dL;
-        if (r0 >= L1ME_SERIES_MIN && r1 >= L1ME_SERIES_MIN && r0 <= L1ME_SERIES_MAX && r1 <= L1ME_SERIES_MAX &&
-            fabs(z) <= 0.1) {
-            const double z2 = z * z;
-            const double at = z * (2.0 + z2 * (0.66666666666666663 + z2 * (0.4 + z2 * (0.2857142857142857 + z2 * (0.22222222222222221 +
-                              z2 * (0.18181818181818182 + z2 * (0.15384615384615385 + z2 * 0.13333333333333333)))))));
-            const double a2 = r0 * r0, b2 = r1 * r1;
-            const double g0 = r0 * (-0.5 + r0 * (4.1666666666666664e-2 - a2 * (3.4722222222222224e-4 - a2 * (5.5114638447971785e-6 - a2 * 1.0333994708994709e-7))));
-            const double g1 = r1 * (-0.5 + r1 * (4.1666666666666664e-2 - b2 * (3.4722222222222224e-4 - b2 * (5.5114638447971785e-6 - b2 * 1.0333994708994709e-7))));
-            dL = at + (g1 - g0);
-        } else {
-            dL = log1mexp(r1, ltab) - log1mexp(r0, ltab);
-        }
-        out += K0 * dL;
-    }
-    return out;
-}
-
 // log of a small positive integer-valued double (counts, bounds): table log; log 1 = 0 exactly
 __device__ __forceinline__ double mv_log(double x, const double2 *ltab) { return x == 1.0 ? 0.0 : fast_log(x, ltab); }
 

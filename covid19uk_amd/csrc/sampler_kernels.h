@@ -872,6 +872,37 @@ __device__ inline void cell_terms(const Dims &d, double S, double E, double I, d
     th += (kir != 0.0 ? kir * L_ir : 0.0) - (I - kir) * r_ir;
 }
 
+// Change of the S->E term of a cell whose F moves by dF while its own state is unchanged:
+//   k [L(r1) - L(r0)] - (S-k)(r1 - r0),  L(r) = log(1-exp(-r)),  r1 = r0 + a.
+// In the small-rate regime L(r1)-L(r0) = log(r1/r0) + g(r1) - g(r0) with log(r1/r0) = 2 atanh(z),
+// z = a/(2 r0 + a): one reciprocal and two short polynomials instead of two table logs, and more
+// accurate than differencing them.
+__device__ __forceinline__ double band_delta(double S, double I, double K0, double F, double dF, double ee,
+                                             double psiW, double floor_dt, double dt, const double2 *ltab) {
+    const double r0 = ee * (I + psiW * F) * dt + floor_dt;
+    const double a = ee * psiW * dF * dt;
+    const double r1 = r0 + a;
+    double out = -(S - K0) * a;
+    if (K0 != 0.0) {
+        const double z = a * fast_rcp(r0 + r1);
+        double dL;
+        if (r0 >= L1ME_SERIES_MIN && r1 >= L1ME_SERIES_MIN && r0 <= L1ME_SERIES_MAX && r1 <= L1ME_SERIES_MAX &&
+            fabs(z) <= 0.1) {
+            const double z2 = z * z;
+            const double at = z * (2.0 + z2 * (0.66666666666666663 + z2 * (0.4 + z2 * (0.2857142857142857 + z2 * (0.22222222222222221 +
+                              z2 * (0.18181818181818182 + z2 * (0.15384615384615385 + z2 * 0.13333333333333333)))))));
+            const double a2 = r0 * r0, b2 = r1 * r1;
+            const double g0 = r0 * (-0.5 + r0 * (4.1666666666666664e-2 - a2 * (3.4722222222222224e-4 - a2 * (5.5114638447971785e-6 - a2 * 1.0333994708994709e-7))));
+            const double g1 = r1 * (-0.5 + r1 * (4.1666666666666664e-2 - b2 * (3.4722222222222224e-4 - b2 * (5.5114638447971785e-6 - b2 * 1.0333994708994709e-7))));
+            dL = at + (g1 - g0);
+        } else {
+            dL = log1mexp(r1, ltab) - log1mexp(r0, ltab);
+        }
+        out += K0 * dL;
+    }
+    return out;
+}
+
 // k_move_delta: log-likelihood change of the pending proposal, over the cells it touches.
 // grid (nrb_d, B).  Rows that only see a changed F (E->I moves): one wave per row, lanes
 // over the days of the hull.  The (<= m) rows whose own state changes carry the expensive
@@ -883,8 +914,26 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
     int bx = blockIdx.x, by = blockIdx.y;
     if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
     const int b = d.b0 + by, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef SEIR_STAMPS
+#ifndef SEIR_STAMP_SLOT
+#define SEIR_STAMP_SLOT 1
+#endif
+#ifndef SEIR_STAMP_BLOCK
+#define SEIR_STAMP_BLOCK 0
+#endif
+    double *dst_hs = ch.hs + (size_t)b * NHS;
+#define DSTAMP(i) do { if (threadIdx.x == 0 && b == 0 && bx == SEIR_STAMP_BLOCK && dstamp_on) ((unsigned long long *)(dst_hs + 16))[12 + i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    bool dstamp_on = true;
+#else
+#define DSTAMP(i) do {} while (0)
+#endif
+    DSTAMP(0);
     if (threadIdx.x == 0) mv = ch.mv[(size_t)buf * s.B + b];
     log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes mv
+#ifdef SEIR_STAMPS
+    dstamp_on = mv.slot == SEIR_STAMP_SLOT;
+#endif
+    DSTAMP(1);
     double dth = 0.0, dcn = 0.0;
     if (mv.valid && mv.n > 0) {
         const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
@@ -913,13 +962,11 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
                     if (dF == 0.0) continue;
                     const double S = w.St[0][rowoff + t], I = w.St[2][rowoff + t], kse = w.K[0][rowoff + t];
                     const double F = w.F[rowoff + t];
-                    const double ee = ea[t] * eb, psiW = psi * c.W[t];
-                    const double r0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
-                    const double r1 = (ee * (I + psiW * (F + dF)) + d.rate_floor) * d.dt;
-                    dth += (kse != 0.0 ? kse * (log1mexp(r1, ltab) - log1mexp(r0, ltab)) : 0.0) - (S - kse) * (r1 - r0);
+                    dth += band_delta(S, I, kse, F, dF, ea[t] * eb, psi * c.W[t], d.rate_floor * d.dt, d.dt, ltab);
                 }
             }
         }
+        DSTAMP(2);
         for (int i0 = 0; i0 < mv.n; ++i0) {
             const int j = mv.m[i0];
             if (j < r_lo || j >= r_hi) continue;     // block-uniform
@@ -961,6 +1008,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
             }
         }
     }
+    DSTAMP(3);
     dth = wave_sum(dth);
     dcn = wave_sum(dcn);
     if (lane == 0) { sh_th[wave] = dth; sh_cn[wave] = dcn; }

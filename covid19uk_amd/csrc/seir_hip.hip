@@ -683,7 +683,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     c.chain0 = ds->first_chain_id;
     c.adapt_step = 0; c.adapt_mass = 0; c.n_adapt = 0; c.target_accept = 0.75;
     c.cap = ds->trace_capacity;
-    c.nrb_d = (d.M + 7) / 8;
+    c.nrb_d = (d.M + 7) / 8;        // row blocks of the move kernels (4 rows per block measured slower: more blocks in k_move_pa2)
     s->record_events = ds->record_events;
     s->use_graph = getenv("SEIR_NO_GRAPH") == nullptr;
     {

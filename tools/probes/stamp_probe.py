@@ -34,6 +34,8 @@ with SeirModel(cov, init, max_chains=B) as model:
                   "stage rows", (st[6]-st[5])*10, "select days", (st[7]-st[6])*10, "mins", (st[8]-st[7])*10,
                   "finish lanes", (st[9]-st[8])*10, "compact", (st[10]-st[9])*10, "store", (st[11]-st[10])*10,
                   "ns ; total", (st[11]-st[0])*10)
+            print("k_move_delta block", os.environ.get("STAMP_BLOCK", "0"), ": mv+ltab", (st[13]-st[12])*10, "band", (st[14]-st[13])*10,
+                  "own rows", (st[15]-st[14])*10, "ns")
             names = []
             for i, v in enumerate(st):
                 v = int(v)
