@@ -685,7 +685,14 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     c.cap = ds->trace_capacity;
     c.nrb_d = (d.M + 7) / 8;        // row blocks of the move kernels (4 rows per block measured slower: more blocks in k_move_pa2)
     s->record_events = ds->record_events;
-    s->use_graph = getenv("SEIR_NO_GRAPH") == nullptr;
+    // Launch mode of a sweep's ~76 dependent kernels.  Measured on MI355X / ROCm 7.2 (UK-380, 8 chains):
+    // stream launches 0.815 ms per sweep, replay of the captured hipGraph 0.872 ms -- the graph
+    // executor costs ~0.75 us more per node than the stream path while the host (3-4 us per launch,
+    // kernels of ~10 us) stays ahead either way.  Default: stream launches; SEIR_GRAPH=1 selects the graph.
+    {
+        const char *e = getenv("SEIR_GRAPH");
+        s->use_graph = e && atoi(e) != 0 && getenv("SEIR_NO_GRAPH") == nullptr;
+    }
     {
         const char *e = getenv("SEIR_MOVES");
         s->legacy_moves = e && strcmp(e, "legacy") == 0;

@@ -192,13 +192,15 @@ def test_chains_are_independent_of_batch_composition(api):
     assert np.array_equal(tr_all.hmc["target_log_prob"][:, 2], tr_one.hmc["target_log_prob"][:, 0])
 
 
-@pytest.mark.parametrize("B,groups,affinity", [(8, 1, "3"), (8, 1, "0"), (3, 1, "3"), (16, 1, "3"), (8, 2, "3"), (6, 4, "3")])
-def test_launch_geometries_give_identical_chains(api, monkeypatch, B, groups, affinity):
+@pytest.mark.parametrize("B,groups,affinity,graph", [(8, 1, "3", "0"), (8, 1, "0", "0"), (3, 1, "3", "0"), (16, 1, "3", "0"),
+                                                    (8, 2, "3", "0"), (6, 4, "3", "0"), (8, 1, "3", "1"), (6, 2, "3", "1")])
+def test_launch_geometries_give_identical_chains(api, monkeypatch, B, groups, affinity, graph):
     """Block-to-chain mappings (XCD affinity for 1/2/4/8 chains per launch, natural grids
     otherwise, chain groups on separate streams) only move work around: every chain's trace must
-    be bit-identical to the same chain run alone."""
+    be bit-identical to the same chain run alone, under stream launches and under graph replay."""
     monkeypatch.setenv("SEIR_CHAIN_GROUPS", str(groups))
     monkeypatch.setenv("SEIR_XCD_AFFINITY", affinity)
+    monkeypatch.setenv("SEIR_GRAPH", graph)              # stream launches (default) or hipGraph replay
     SeirModel, ChainSampler = api
     case = H.build_case("micro_17x70", 9, alpha_t_sd=0.005)
     u, ev = _start(case, B, 9)
@@ -209,6 +211,7 @@ def test_launch_geometries_give_identical_chains(api, monkeypatch, B, groups, af
             s.set_kernel(step_size=0.0004)
             tr_all = s.sample(n)
     monkeypatch.setenv("SEIR_CHAIN_GROUPS", "1")
+    monkeypatch.setenv("SEIR_GRAPH", "0")
     for b in (0, B - 1):
         with SeirModel(case["cov"], case["init"], max_chains=1) as model:
             with ChainSampler(model, CFG_SMALL, 1, seed=5, first_chain_id=b, trace_capacity=n) as s:
