@@ -169,6 +169,32 @@ def test_running_log_prob_matches_full_reevaluation_uk380(api):
         assert abs(tr.moves["occult/E->I"]["target_log_prob"][-1, b] - lp_run[b]) <= 1e-12 * abs(want)
 
 
+def test_running_log_prob_matches_full_reevaluation_syn2048(api):
+    """BASELINE's largest configuration (2048 regions x 730 days, T and M beyond one 512-thread
+    pass of the single-workgroup kernels): two sweeps, then the same bookkeeping checks."""
+    SeirModel, ChainSampler = api
+    case = H.build_case("syn2048", 3)
+    B, n = 2, 2
+    u, ev = _start(case, B, 3, scale=0.001)
+    u[:, 6:6 + case["k"].T - 1] = 0.0
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, CFG_REF, B, seed=4, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=2e-6)
+            tr = s.sample(n)
+            u1, ev1, lp_run = s.get_state()
+            s.refresh()
+            lp_fresh = s.log_prob()
+    assert np.isfinite(lp_run).all()
+    assert sum(int(tr.moves[k]["is_accepted"].sum()) for k in tr.moves) > 0
+    for b in range(B):
+        want = H.c_oracle_eval(case["k"], u1[b], ev1[b], stable=1)
+        assert abs(lp_run[b] - want) <= 1e-9 * abs(want), (b, lp_run[b], want)
+        assert abs(lp_fresh[b] - want) <= 1e-9 * abs(want)
+        assert so.compute_state(case["init"], ev1[b], closed=True).min() >= 0
+        assert np.array_equal(tr.events[-1, b], ev1[b].astype(np.int32))
+
+
 def test_chains_are_independent_of_batch_composition(api):
     """Chain c's draws depend only on (seed, global chain id): running chains {0,1,2,3}
     together or chain 2 alone (first_chain_id=2) gives bit-identical traces -- the
