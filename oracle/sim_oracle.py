@@ -101,6 +101,12 @@ def binomial(n, p, uniform):
     return n - x if flip else int(x)
 
 
+def _prob(rate_dt):
+    """1 - exp(-rate dt); a (meaningless) negative rate gives a negative "probability", which the
+    binomial sampler treats as 0 -- fp64 overflow of exp included, as on the device."""
+    return float("-inf") if rate_dt < -700.0 else -math.expm1(-rate_dt)
+
+
 def day_rates(state, par, a_t, W_t, wd_t, k: so.ModelConstants):
     """model_spec.py:257-274 for one day: state [M,4] -> (rate_se[M], rate_ei, rate_ir)."""
     psi, sigma, beta, g0, g1 = (float(par[i]) for i in range(5))
@@ -126,11 +132,11 @@ def simulate(k: so.ModelConstants, par, log_baseline, spatial, W, weekday_c, ini
         th = np.concatenate([par[d], np.asarray(spatial[d], dtype=np.float64)])
         for s in range(S):
             lam, nu, rir = day_rates(state, th, float(log_baseline[d][s]), float(W[s]), float(weekday_c[s]), k)
-            p_ei = -math.expm1(-nu * dt)
-            p_ir = -math.expm1(-rir * dt)
+            p_ei = _prob(nu * dt)
+            p_ir = _prob(rir * dt)
             for m in range(M):
                 cell = s * M + m
-                p_se = -math.expm1(-float(lam[m]) * dt)
+                p_se = _prob(float(lam[m]) * dt)
                 for x, (src, p) in enumerate(((0, p_se), (1, p_ei), (2, p_ir))):
                     y = binomial(state[m, src], p,
                                  lambda att, x=x: _u(seed, first_draw_id + d, cell, x, att))

@@ -216,3 +216,32 @@ def test_predict_end_to_end(tmp_path):
     want = sim.simulate(k, theta[:, :5], a_path, theta[:, 6 + k.T - 1:], pp.clipped(k.W, 3, 10),
                         pp.clipped(k.weekday_c, 3, 10), init2, seed=8)
     assert np.array_equal(ev2, want)
+
+
+@pytest.mark.gpu
+def test_simulate_argument_errors_and_degenerate_inputs():
+    import __graft_entry__ as entry
+    entry.build()
+    from covid19uk_amd import _lib
+    from covid19uk_amd.seir import SeirModel
+    case = H.build_case("micro_3x5", 2)
+    par, a_path, spatial, W, wd, init = _sim_inputs(case, 2, 4, 1)
+    with SeirModel(case["cov"], case["init"], max_chains=1) as model:
+        with pytest.raises(ValueError):
+            model.simulate(par[:, :4], a_path, spatial, W, wd, init)
+        with pytest.raises(ValueError):
+            model.simulate(par, a_path, spatial, W[:-1], wd, init)
+        with pytest.raises(_lib.SeirError):
+            model.simulate(par[:0], a_path[:0], spatial[:0], W, wd, init[:0])     # no draws
+        # nobody infected, nobody exposed: nothing can happen except the 1e-9 rate floor on S
+        quiet = init.copy()
+        quiet[:, :, 1:3] = 0
+        ev = model.simulate(par, a_path, spatial, W, wd, quiet, seed=3)
+        assert ev[..., 1:].sum() == 0 and ev[..., 0].sum() <= 1
+        # a negative force of infection (psi * Cstar diagonal dominating) is clamped to probability 0
+        neg = par.copy()
+        neg[:, 0] = 1e9
+        ev = model.simulate(neg, a_path, spatial, W, wd, init, seed=3)
+        assert np.all(ev >= 0) and np.all(so.compute_state(init, ev) >= 0)
+        want = sim.simulate(case["k"], neg, a_path, spatial, W, wd, init, seed=3)
+        assert np.array_equal(ev, want)
