@@ -625,6 +625,269 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_move_pair: one launch per PAIR of event updates (S->E-type, then E->I-type).
+//
+// An S->E update (event-time move or occult) changes only the rows it touches: no other row's
+// force of infection moves, so its whole Metropolis-Hastings step -- propose, log-ratio over the
+// updated rows, accept test, state update, trace -- is local to the workgroup that proposes it.
+// Only the E->I updates need the chip (F moves on a band of days for every row).  The launch
+// therefore does, in order:
+//   (1) every block: finalize the pending E->I-type proposal (accept test from k_move_delta's
+//       partial sums; F band update by all blocks; rows, trace by block 0)      [as k_move_pa2]
+//   (2) block 0: the complete S->E-type update `se`
+//   (3) block 0: draw the E->I-type proposal `next` for the following k_move_delta
+// which takes a scan from 8 launches to 4.  se.kind < 0: no S->E update; next.kind == -2: closing
+// launch of the sweep (advance the counter).  Random streams, proposal arithmetic and the order
+// of the four updates are those of k_move_pa2 / the oracle.
+// grid (nrb_d, B) or its XCD-affine 1-D form, MVB threads.
+// ---------------------------------------------------------------------------------------------
+constexpr int PRE_RT = 4;                                      // prefetched rows per thread (M <= 2048)
+
+// row totals (kind 0) or per-row events inside the occult range (kind 1) of plane spec.tgt
+__device__ __forceinline__ void mv_prefetch_rows(const Dims &d, const Work &w, const SamplerCfg &s, int b, MoveSpec spec,
+                                                 bool on, int (&pre)[PRE_RT]) {
+    const int tid = threadIdx.x, R = s.tr_hi - s.tr_lo;
+#pragma unroll
+    for (int k = 0; k < PRE_RT; ++k) {
+        const int m = tid + k * MVB;
+        pre[k] = 0;
+        if (on && m < d.M) {
+            if (spec.kind == 0) {
+                pre[k] = w.rowtot[((size_t)b * 2 + spec.tgt) * d.Mp + m];
+            } else {
+                const int *kr = w.K[spec.tgt] + ((size_t)b * d.Mp + m) * d.Tp + s.tr_lo;
+                int acc = 0;
+                for (int t0 = 0; t0 < R; t0 += 32) {           // one batch at the reference's 21-day range
+                    int v[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) v[j] = t0 + j < R ? kr[t0 + j] : 0;
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) acc += v[j];
+                }
+                pre[k] = acc;
+            }
+        }
+    }
+}
+
+// publish the prefetched values in LDS, corrected for an update of the same plane that was
+// accepted after the prefetch (`fix` != nullptr); falls back to fresh loads when M is too large
+__device__ __forceinline__ void mv_rows_to_lds(const Dims &d, const Work &w, const SamplerCfg &s, int b, MoveSpec spec,
+                                               bool pre_ok, const int (&pre)[PRE_RT], const Move *fix, MvLds &L,
+                                               int *rtl) {
+    const int tid = threadIdx.x, M = d.M;
+    int *dst = spec.kind == 0 ? rtl : L.rg;
+    if (pre_ok) {
+#pragma unroll
+        for (int k = 0; k < PRE_RT; ++k) {
+            const int m = tid + k * MVB;
+            if (m < M) dst[m] = pre[k];
+        }
+        lds_barrier();
+        if (fix && tid == 0)
+            for (int i = 0; i < fix->n; ++i) {
+                if (spec.kind == 0) {
+                    dst[fix->m[i]] += fix->dka[i] + fix->dkb[i];
+                } else {
+                    if (fix->a[i] >= s.tr_lo && fix->a[i] < s.tr_hi) dst[fix->m[i]] += fix->dka[i];
+                    if (fix->b[i] >= s.tr_lo && fix->b[i] < s.tr_hi) dst[fix->m[i]] += fix->dkb[i];
+                }
+            }
+        lds_barrier();
+    } else {
+        __syncthreads();                                      // this block's own stores to the planes
+        if (spec.kind == 0) {
+            for (int m = tid; m < M; m += MVB) dst[m] = w.rowtot[((size_t)b * 2 + spec.tgt) * d.Mp + m];
+            lds_barrier();
+        } else {
+            range_totals_to_lds(d, w, s, b, spec.tgt, L.rg);
+        }
+    }
+}
+
+// state update of an accepted proposal by the calling block (rows, events, row totals, I->R
+// exposure); ends with the stores drained
+__device__ __forceinline__ void mv_apply_rows(const Dims &d, const Work &w, int b, const Move &mv) {
+    const int tid = threadIdx.x;
+    for (int i = 0; i < mv.n; ++i) {
+        const size_t rowoff = ((size_t)b * d.Mp + mv.m[i]) * d.Tp;
+        const int src = mv.tgt, dst = mv.tgt + 1;
+        for (int t = mv.lo[i] + 1 + tid; t <= mv.hi[i]; t += MVB) {
+            w.St[src][rowoff + t] += mv.dsrc[i];
+            w.St[dst][rowoff + t] -= mv.dsrc[i];
+            if (mv.tgt == 1) w.Dir[(size_t)b * d.Tp + t] -= (double)mv.dsrc[i];
+        }
+        if (tid == 0) {
+            w.K[mv.tgt][rowoff + mv.a[i]] += mv.dka[i];
+            if (mv.b[i] >= 0) w.K[mv.tgt][rowoff + mv.b[i]] += mv.dkb[i];
+            w.rowtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += mv.dka[i] + mv.dkb[i];
+        }
+        __syncthreads();     // two updates may touch the same cells
+    }
+}
+
+// trace row of one update (thread 0)
+__device__ __forceinline__ void mv_trace(const SamplerCfg &s, const Chains &ch, int b, const Move &mv, int acc,
+                                         unsigned tr_slot, double lp) {
+    if (tr_slot < (unsigned)s.cap) {
+        double *tr = ch.tr_mv + (((size_t)tr_slot * s.B + b) * 4 + mv.slot) * NMVTR;
+        tr[0] = (double)acc;
+        tr[1] = lp;
+        for (int j = 0; j < MMAX; ++j) {
+            tr[2 + j] = mv.tm[j]; tr[2 + MMAX + j] = mv.tt[j];
+            tr[2 + 2 * MMAX + j] = mv.tdt[j]; tr[2 + 3 * MMAX + j] = mv.tx[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
+                                                   MoveSpec next, int have_prev, int pbuf) {
+    extern __shared__ int dyn_i[];                     // block 0: rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
+    __shared__ MvShared sm_se, sm_nx;
+    __shared__ Move pend;
+    __shared__ double2 ltab[LDSTAB_N];
+    __shared__ int s_acc, s_acc_se;
+    __shared__ double s_dth, s_dcn;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
+    const int b = d.b0 + by, tid = threadIdx.x;
+    const int M = d.M, T = d.T;
+    const bool do_se = bx == 0 && se.kind >= 0, do_nx = bx == 0 && next.kind >= 0;
+#ifdef SEIR_STAMPS
+    double *stamp_hs = ch.hs + (size_t)b * NHS;
+    const bool stamp_on = do_se && b == 0 && se.slot == (SEIR_STAMP_SLOT & 2) && se.scan == 0;
+#define PSTAMP(i) do { if (threadIdx.x == 0 && stamp_on) ((unsigned long long *)(stamp_hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
+    PSTAMP(0);
+    // ---- entry: everything that does not depend on a decision made in this launch
+    const bool pre_ok = M <= PRE_RT * MVB;
+    int pre_se[PRE_RT], pre_nx[PRE_RT];
+    mv_prefetch_rows(d, w, s, b, se, do_se && pre_ok, pre_se);
+    mv_prefetch_rows(d, w, s, b, next, do_nx && pre_ok, pre_nx);
+    double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
+    unsigned tr_slot = 0xffffffffu;
+    if (bx == 0) {
+        if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
+        if (tid == 0) {
+            const double *hs = ch.hs + (size_t)b * NHS;
+            hs_th = hs[HS_LP_THETA]; hs_cn = hs[HS_LP_CONST];
+            tr_slot = ch.sweep[b] - ch.slot0[0];
+        }
+        if (do_se) {
+            psi = w.scal[(size_t)b * NSCAL + SC_PSI];
+            mv_draw(s, ch, b, se, sm_se, T);
+        }
+        if (do_nx) mv_draw(s, ch, b, next, sm_nx, T);
+    }
+    // ---- (1) finalize the pending E->I-type proposal
+    bool pend_acc = false;
+    if (have_prev) {
+        if (tid == 0) pend = ch.mv[(size_t)pbuf * s.B + b];
+        double dth = 0.0, dcn = 0.0;
+        for (int i = tid; i < s.nrb_d; i += MVB) {
+            dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
+            dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
+        }
+        mv_sum2(dth, dcn, sm_nx.dred);
+        if (tid == 0) {
+            const double ratio = dth + dcn + pend.logq;
+            s_acc = (pend.valid && pend.logu < ratio) ? 1 : 0;   // NaN -> reject
+            s_dth = dth; s_dcn = dcn;
+        }
+        __syncthreads();
+        pend_acc = s_acc != 0;
+        const Move &mv = pend;
+        if (pend_acc && mv.any_dI) {
+            // F[j][t] += sum_i Cstar[j][m_i] dI_i / N_{m_i}  on each update's day window
+            const int rows_per_blk = (M + s.nrb_d - 1) / s.nrb_d;
+            const int r_lo = bx * rows_per_blk, r_hi = min(M, r_lo + rows_per_blk);
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int j = r_lo + wave; j < r_hi; j += MVW) {
+                double coef[MMAX];
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                                       : 0.0;
+                double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
+                for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
+                    double dF = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MMAX; ++i)
+                        if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+                    if (dF != 0.0) Fr[t] += dF;
+                }
+            }
+        }
+        if (bx == 0) {
+            if (pend_acc) mv_apply_rows(d, w, b, mv);
+            if (tid == 0) {
+                if (pend_acc) {
+                    double *hs = ch.hs + (size_t)b * NHS;
+                    hs_th += s_dth; hs_cn += s_dcn;
+                    hs[HS_LP_THETA] = hs_th; hs[HS_LP_CONST] = hs_cn;
+                }
+                mv_trace(s, ch, b, mv, s_acc, tr_slot, hs_th + hs_cn);
+            }
+            lds_barrier();
+        }
+    }
+    if (bx != 0) return;
+    PSTAMP(1);
+    MvLds L{};
+    int *rtl = dyn_i + M;
+    L.rt = rtl;
+    L.rstride = 0;
+    L.rg = dyn_i;
+    L.rk = dyn_i + 2 * M;
+    L.rsrc = L.rk + MMAX * (T + 1);
+    L.rdst = L.rsrc + MMAX * (T + 1);
+    // ---- (2) the whole S->E-type update
+    if (do_se) {
+        // the pending update was of the other plane (tgt 1): nothing to correct in plane 0's totals
+        mv_rows_to_lds(d, w, s, b, se, pre_ok, pre_se, nullptr, L, rtl);
+        PSTAMP(2);
+        mv_propose(d, w, s, ch, b, se, sm_se, L, ltab);
+        PSTAMP(3);
+        const Move &mv = sm_se.mv;
+        double dth = 0.0, dcn = 0.0;
+        if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, M, ltab, dth, dcn);
+        PSTAMP(4);
+        mv_sum2(dth, dcn, sm_se.dred);
+        if (tid == 0) {
+            const double ratio = dth + dcn + mv.logq;
+            s_acc_se = (mv.valid && mv.logu < ratio) ? 1 : 0;    // NaN -> reject
+        }
+        lds_barrier();
+        const bool acc = s_acc_se != 0;
+        if (acc) mv_apply_rows(d, w, b, mv);
+        if (tid == 0) {
+            if (acc) {
+                double *hs = ch.hs + (size_t)b * NHS;
+                hs_th += dth; hs_cn += dcn;
+                hs[HS_LP_THETA] = hs_th; hs[HS_LP_CONST] = hs_cn;
+            }
+            mv_trace(s, ch, b, mv, s_acc_se, tr_slot, hs_th + hs_cn);
+        }
+        __syncthreads();             // rows staged for (3) must see the state written above
+        PSTAMP(5);
+    }
+    // ---- (3) proposal for the following k_move_delta; closing launch: advance the sweep counter
+    if (next.kind == -2 && tid == 0) ch.sweep[b] += 1;
+    if (do_nx) {
+        // plane 1 totals were prefetched before (1): correct them if the pending (plane 1) update was accepted
+        const Move *fix = (have_prev && pend_acc && pend.tgt == next.tgt) ? &pend : nullptr;
+        mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
+        PSTAMP(6);
+        mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
+        if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
+        PSTAMP(7);
+    }
+}
+
+
 inline size_t k_move_pa2_lds_bytes(const Dims &d) {
     return sizeof(int) * ((size_t)2 * d.M + 3 * MMAX * (d.T + 1));
 }

@@ -872,6 +872,58 @@ __device__ inline void cell_terms(const Dims &d, double S, double E, double I, d
     th += (kir != 0.0 ? kir * L_ir : 0.0) - (I - kir) * r_ir;
 }
 
+// Log-ratio contribution of the rows a proposal updates (their own state and events change, and
+// for E->I updates F moves as well): sum over the touched days of [terms(new) - terms(old)].
+// Rows outside [r_lo, r_hi) are skipped (k_move_delta: the block that owns the row; the fused
+// S->E kernel passes the whole range).  NT threads of the calling block take part.
+template <int NT>
+__device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, const Work &w, int b, const Move &mv,
+                                               double psi, int r_lo, int r_hi, const double2 *ltab, double &dth,
+                                               double &dcn) {
+    const double r_ei = d.nu * d.dt, L_ei = d.L_ei;
+    const double *ea = w.ea + (size_t)b * d.Tp;
+    for (int i0 = 0; i0 < mv.n; ++i0) {
+        const int j = mv.m[i0];
+        if (j < r_lo || j >= r_hi) continue;     // block-uniform
+        const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
+        const double eb = w.eb[(size_t)b * d.Mp + j];
+        double coef[MMAX];
+#pragma unroll
+        for (int i = 0; i < MMAX; ++i)
+            coef[i] = (i < mv.n && mv.tgt == 1)
+                          ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                          : 0.0;
+        for (int t = mv.LO + (int)threadIdx.x; t <= mv.HI; t += NT) {
+            double dF = 0.0;
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+            const bool in_state = t > mv.lo[i0] && t <= mv.hi[i0];
+            int dS = 0, dE = 0, dI = 0, dkt = 0;
+            if (in_state) {
+                if (mv.tgt == 0) { dS = mv.dsrc[i0]; dE = -mv.dsrc[i0]; }
+                else { dE = mv.dsrc[i0]; dI = -mv.dsrc[i0]; }
+            }
+            if (t == mv.a[i0]) dkt += mv.dka[i0];
+            if (t == mv.b[i0]) dkt += mv.dkb[i0];
+            if (dS == 0 && dE == 0 && dI == 0 && dkt == 0 && dF == 0.0) continue;
+            const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
+            const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
+            const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
+            const double F = w.F[rowoff + t];
+            const double ee = ea[t] * eb, psiW = psi * c.W[t];
+            const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
+            const double L_ir = log1mexp(r_ir, ltab);
+            double th0, cn0, th1, cn1;
+            cell_terms(d, S, E, I, kse, kei, kir, F, ee, psiW, r_ir, L_ir, L_ei, r_ei, ltab, th0, cn0);
+            cell_terms(d, S + dS, E + dE, I + dI, kse + dk0, kei + dk1, kir, F + dF, ee, psiW, r_ir, L_ir, L_ei,
+                       r_ei, ltab, th1, cn1);
+            dth += th1 - th0;
+            dcn += cn1 - cn0;
+        }
+    }
+}
+
 // Change of the S->E term of a cell whose F moves by dF while its own state is unchanged:
 //   k [L(r1) - L(r0)] - (S-k)(r1 - r0),  L(r) = log(1-exp(-r)),  r1 = r0 + a.
 // In the small-rate regime L(r1)-L(r0) = log(r1/r0) + g(r1) - g(r0) with log(r1/r0) = 2 atanh(z),
@@ -967,46 +1019,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
             }
         }
         DSTAMP(2);
-        for (int i0 = 0; i0 < mv.n; ++i0) {
-            const int j = mv.m[i0];
-            if (j < r_lo || j >= r_hi) continue;     // block-uniform
-            const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
-            const double eb = w.eb[(size_t)b * d.Mp + j];
-            double coef[MMAX];
-#pragma unroll
-            for (int i = 0; i < MMAX; ++i)
-                coef[i] = (i < mv.n && mv.tgt == 1)
-                              ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
-                              : 0.0;
-            for (int t = mv.LO + (int)threadIdx.x; t <= mv.HI; t += 256) {
-                double dF = 0.0;
-#pragma unroll
-                for (int i = 0; i < MMAX; ++i)
-                    if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
-                const bool in_state = t > mv.lo[i0] && t <= mv.hi[i0];
-                int dS = 0, dE = 0, dI = 0, dkt = 0;
-                if (in_state) {
-                    if (mv.tgt == 0) { dS = mv.dsrc[i0]; dE = -mv.dsrc[i0]; }
-                    else { dE = mv.dsrc[i0]; dI = -mv.dsrc[i0]; }
-                }
-                if (t == mv.a[i0]) dkt += mv.dka[i0];
-                if (t == mv.b[i0]) dkt += mv.dkb[i0];
-                if (dS == 0 && dE == 0 && dI == 0 && dkt == 0 && dF == 0.0) continue;
-                const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
-                const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
-                const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
-                const double F = w.F[rowoff + t];
-                const double ee = ea[t] * eb, psiW = psi * c.W[t];
-                const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
-                const double L_ir = log1mexp(r_ir, ltab);
-                double th0, cn0, th1, cn1;
-                cell_terms(d, S, E, I, kse, kei, kir, F, ee, psiW, r_ir, L_ir, L_ei, r_ei, ltab, th0, cn0);
-                cell_terms(d, S + dS, E + dE, I + dI, kse + dk0, kei + dk1, kir, F + dF, ee, psiW, r_ir, L_ir, L_ei,
-                           r_ei, ltab, th1, cn1);
-                dth += th1 - th0;
-                dcn += cn1 - cn0;
-            }
-        }
+        own_rows_delta<256>(d, c, w, b, mv, psi, r_lo, r_hi, ltab, dth, dcn);
     }
     DSTAMP(3);
     dth = wave_sum(dth);

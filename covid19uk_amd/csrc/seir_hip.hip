@@ -620,6 +620,7 @@ struct seir_sampler {
     std::vector<hipEvent_t> ev_join;
     bool use_graph = true;
     bool legacy_moves = false;    // SEIR_MOVES=legacy: first implementation of the proposal kernel (k_move_pa)
+    int moves_mode = 0;           // 0 = paired launches (k_move_pair); 1 = one proposal kernel per update (split / legacy)
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
 };
@@ -694,8 +695,10 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         s->use_graph = e && atoi(e) != 0 && getenv("SEIR_NO_GRAPH") == nullptr;
     }
     {
+        // SEIR_MOVES: (default) paired launches | "split": k_move_pa2 per update | "legacy": k_move_pa per update
         const char *e = getenv("SEIR_MOVES");
         s->legacy_moves = e && strcmp(e, "legacy") == 0;
+        s->moves_mode = (e && (strcmp(e, "legacy") == 0 || strcmp(e, "split") == 0)) ? 1 : 0;
     }
     {
         const char *e = getenv("SEIR_CHAIN_GROUPS");
@@ -978,28 +981,47 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
         int have_prev = 0, pbuf = 0;
-        for (int scan = 0; scan < c.n_scans; ++scan)
-            for (int slot = 0; slot < 4; ++slot) {
-                const MoveSpec spec{slot >= 2 ? 1 : 0, slot & 1, slot, scan};
-                if (s->legacy_moves)
-                    hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, spec, have_prev,
-                                       pbuf);
-                else
-                    hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
+        if (s->moves_mode == 0) {
+            // paired form: [finalize pending E->I-type | whole S->E-type update | propose E->I-type], then
+            // the log-ratio of the E->I-type proposal over its band: 4 launches per scan
+            for (int scan = 0; scan < c.n_scans; ++scan)
+                for (int half = 0; half < 2; ++half) {
+                    const MoveSpec se{half, 0, 2 * half, scan}, nx{half, 1, 2 * half + 1, scan};
+                    hipLaunchKernelGGL(k_move_pair, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
                                        have_prev, pbuf);
-                pbuf ^= 1;
-                hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf);
-                have_prev = 1;
-            }
-        if (have_prev) {
-            // closing launch: finalize the last proposal; k_move_pa2 also advances the sweep counter
-            if (s->legacy_moves) {
-                const MoveSpec none{-1, 0, 0, 0};
-                hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
-            } else {
-                const MoveSpec none{-2, 0, 0, 0};
-                hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+                    pbuf ^= 1;
+                    hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf);
+                    have_prev = 1;
+                }
+            if (have_prev) {
+                const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
+                hipLaunchKernelGGL(k_move_pair, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, 1, pbuf);
                 advanced = 1;
+            }
+        } else {
+            for (int scan = 0; scan < c.n_scans; ++scan)
+                for (int slot = 0; slot < 4; ++slot) {
+                    const MoveSpec spec{slot >= 2 ? 1 : 0, slot & 1, slot, scan};
+                    if (s->legacy_moves)
+                        hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, spec, have_prev,
+                                           pbuf);
+                    else
+                        hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
+                                           have_prev, pbuf);
+                    pbuf ^= 1;
+                    hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf);
+                    have_prev = 1;
+                }
+            if (have_prev) {
+                // closing launch: finalize the last proposal; k_move_pa2 also advances the sweep counter
+                if (s->legacy_moves) {
+                    const MoveSpec none{-1, 0, 0, 0};
+                    hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+                } else {
+                    const MoveSpec none{-2, 0, 0, 0};
+                    hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+                    advanced = 1;
+                }
             }
         }
     }

@@ -55,7 +55,7 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
             assert np.max(np.abs(trace.theta[i, b] - o["theta"]) / scale) < theta_rtol, (i, b, "theta")
 
 
-@pytest.mark.parametrize("moves", ["default", "legacy"])
+@pytest.mark.parametrize("moves", ["default", "split", "legacy"])
 @pytest.mark.parametrize("name,cfg,seed,eps,n", [
     ("micro_5x24", CFG_SMALL, 1, 0.002, 12),
     ("ni11", CFG_REF, 2, 0.002, 8),
@@ -67,8 +67,8 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
     ("micro_65x65", CFG_SMALL, 7, 0.0001, 3),
 ])
 def test_fixed_kernel_sweeps_match_oracle(api, monkeypatch, name, cfg, seed, eps, n, moves):
-    """Both implementations of the proposal kernel (k_move_pa2 and the first one, k_move_pa)
-    against the oracle."""
+    """The three forms of the event-update launches -- paired (k_move_pair, default), one proposal
+    kernel per update (k_move_pa2) and the first implementation (k_move_pa) -- against the oracle."""
     monkeypatch.setenv("SEIR_MOVES", moves)
     SeirModel, ChainSampler = api
     case = H.build_case(name, seed, alpha_t_sd=0.005)

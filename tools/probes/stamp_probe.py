@@ -29,6 +29,9 @@ with SeirModel(cov, init, max_chains=B) as model:
                   "Rpart+M vectors", (st[12] - st[11]) * 10, "barrier", (st[1] - st[12]) * 10, "ns")
         else:
             st = st.astype(np.int64)
+            print("k_move_pair block 0 (se slot", int(os.environ.get("STAMP_SLOT", "1")) & 2, "): entry+finalize", (st[1]-st[0])*10, "se tables", (st[2]-st[1])*10,
+                  "se propose", (st[3]-st[2])*10, "se delta", (st[4]-st[3])*10, "se accept/apply/trace", (st[5]-st[4])*10,
+                  "nx tables", (st[6]-st[5])*10, "nx propose+store", (st[7]-st[6])*10, "ns; total", (st[7]-st[0])*10)
             print("k_move_pa2 block 0, slot", os.environ.get("STAMP_SLOT", "1"), ": entry->sums", (st[1]-st[0])*10, "finalize", (st[2]-st[1])*10,
                   "tables", (st[3]-st[2])*10, "propose: rng/init", (st[4]-st[3])*10, "select rows", (st[5]-st[4])*10,
                   "stage rows", (st[6]-st[5])*10, "select days", (st[7]-st[6])*10, "mins", (st[8]-st[7])*10,
