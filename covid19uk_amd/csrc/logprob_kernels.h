@@ -34,6 +34,8 @@ struct Dims {
     int b0;                 // first chain handled by this launch (chain groups on separate streams)
     int nrb_scan;           // row blocks of k_scan
     int nmt, ntc;           // k_se tiles: Mp/SE_TM row tiles, Tp/64 day chunks
+    int chunked;            // sampler: k_se also writes the tile scalars of the chunked leapfrog (Work::TS)
+    int sp_par;             // which of the two Work::sp / Work::gst buffers holds the current position
     int aff_nb;             // 0 = natural grids (tile, chain); > 0 = 1-D grids of tiles*aff_nb blocks with chain <-> XCD affinity
     double nu, dt, rate_floor, car_half_logdet;
     double L_ei;            // log(1 - exp(-nu dt))
@@ -70,7 +72,16 @@ struct Work {
     double *Lpart, *Ppart; // [B][nmt*ntc]
     double *Kpart;         // [B][nmt][Tp]
     double *Rpart;         // [B][ntc][Mp]
+    // chunked leapfrog (sampler only; null on a plain context) -- see k_hmc_chunk in sampler_kernels.h
+    double *TS;            // [B][nmt*ntc][4] per k_se tile: sum col, sum col*V(t), sum_m l_m*row, sum_m s_m*row
+    double *sp;            // [B][2][Mp] spatial effect at the position the tables were built for (double-buffered)
+    double *gst;           // [B][2][GST_N] the six global parameters, their momenta, psi, sigma and the two sigmoids
+    double *Vt;            // [B][Tp]  V(t) = sum_{s=1..t} var[alpha_t[s-1]]
+    double *acur;          // [B][Tp]  a_t = alpha_0 + cumsum(alpha_t)[t-1] at the current position
+    double *CT;            // [B][2][CT_MAXC][4] per 64-day chunk: sum alpha, sum v p, sum v alpha (double-buffered)
 };
+constexpr int CT_MAXC = 16;     // Tp/64 <= 16 (T <= 1024)
+constexpr int GST_N = 16;       // q[0..5], p[0..5], psi, sigma_space, sigmoid(u0), sigmoid(u1)
 
 // ---------------------------------------------------------------------------
 // k_scan: one wave per row (m); lanes over days in 64-day chunks with a carry.
@@ -395,6 +406,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     __shared__ double colbuf[4][WAVE];
     __shared__ double llbuf[4][WAVE], psibuf[4][WAVE];
     __shared__ double rowbuf[GRAD ? 4 * SE_RW * SE_RS : 1];
+    __shared__ double rlbuf[4][WAVE], rsbuf[4][WAVE];
     __shared__ double2 ltab[LDSTAB_N];
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (d.aff_nb > 0) {
@@ -428,8 +440,19 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
             kse[r] = (double)ki; snk[r] = (double)(w.St[0][q] - ki);
         }
     }
+    // tile scalars for the chunked leapfrog: operands fetched with the other loads
+    const bool ts_on = GRAD && SRC == 1 && d.chunked != 0;
+    double ts_vt = 0.0, ts_l[SE_RW], ts_s[SE_RW];
+    // the wave's rows are the same for all its lanes: scalar loads, the values live in SGPRs
+    const int m0u = by * SE_TM + __builtin_amdgcn_readfirstlane(wave) * SE_RW;
+#pragma unroll
+    for (int r = 0; r < SE_RW; ++r) {
+        ts_l[r] = ts_on ? c.la[m0u + r] : 0.0;
+        ts_s[r] = ts_on ? w.sp[((size_t)b * 2 + d.sp_par) * d.Mp + m0u + r] : 0.0;
+    }
+    if (ts_on) ts_vt = w.Vt[(size_t)b * d.Tp + t];
     __syncthreads();
-    double ll = 0.0, gpsi = 0.0, colacc = 0.0;
+    double ll = 0.0, gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0;
     double *myrow = rowbuf + (GRAD ? wave * SE_RW * SE_RS : 0);
 #pragma unroll
     for (int r = 0; r < SE_RW; ++r) {
@@ -445,6 +468,8 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
             const double ge = gl * lam0;
             myrow[r * SE_RS + lane] = ge;
             colacc += ge;
+            rlacc = fma(ge, ts_l[r], rlacc);              // sum_m l_m (row sum)_m and sum_m s_m (row sum)_m, cell by cell
+            rsacc = fma(ge, ts_s[r], rsacc);
             gpsi += gl * ee * Wt * F[r];
         }
     }
@@ -464,6 +489,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, WAVE);
         if (ss == 0) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + m0 + rr_] = v;
+        if (ts_on) { rlbuf[wave][lane] = rlacc; rsbuf[wave][lane] = rsacc; }
     }
     __syncthreads();
     const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
@@ -474,8 +500,18 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
         const double v = wave_sum((psibuf[0][lane] + psibuf[1][lane]) + (psibuf[2][lane] + psibuf[3][lane]));
         if (lane == 0) w.Ppart[tile] = v;
     } else if (GRAD && wave == 2) {
-        w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t] =
-            (colbuf[0][lane] + colbuf[1][lane]) + (colbuf[2][lane] + colbuf[3][lane]);
+        const double cs = (colbuf[0][lane] + colbuf[1][lane]) + (colbuf[2][lane] + colbuf[3][lane]);
+        w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t] = cs;
+        if (ts_on) {
+            const double bs = wave_sum(cs), as = wave_sum(cs * ts_vt);
+            if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
+        }
+    } else if (GRAD && wave == 3) {
+        if (ts_on) {
+            const double rl = wave_sum((rlbuf[0][lane] + rlbuf[1][lane]) + (rlbuf[2][lane] + rlbuf[3][lane]));
+            const double rs = wave_sum((rsbuf[0][lane] + rsbuf[1][lane]) + (rsbuf[2][lane] + rsbuf[3][lane]));
+            if (lane == 0) { w.TS[tile * 4 + 2] = rl; w.TS[tile * 4 + 3] = rs; }
+        }
     }
 }
 

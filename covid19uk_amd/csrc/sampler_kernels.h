@@ -197,8 +197,10 @@ __device__ __forceinline__ double block_incl_suffix_hb(double v, double *sh, dou
     return inc + tail;
 }
 
+// gather_qs != 0: (Q s) of the current position is gathered from q instead of read from w.Qs (the
+// chunked leapfrog steps before this launch do not maintain w.Qs).
 template <int STAGE, int HT, int HM>
-__global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, SamplerCfg s, Chains ch) {
+__global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int gather_qs) {
     extern __shared__ double lds_sp[];                 // [Mp] spatial_effect of the new position
     __shared__ double red[HWV * NRED];
     __shared__ double scn[HWV];
@@ -299,7 +301,26 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         for (int i = 0; i < 6; ++i) { q6[i] = q[i]; p6[i] = STAGE == 0 ? 0.0 : p[i]; v6[i] = var[i]; }
     }
     STAMP_DRAIN(12);
-    lds_barrier();                                     // ltab
+    if (gather_qs) {                                   // uniform branch
+#pragma unroll
+        for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; if (m < M) lds_sp[m] = qm[k]; }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < HM; ++k) {
+            const int m = tid + k * HB;
+            if (m < M) {
+                double acc = 0.0;
+                if (ell_pre) {
+#pragma unroll
+                    for (int j = 0; j < QPRE; ++j) acc += qell_v[k][j] * lds_sp[qell_c[k][j]];
+                } else {
+                    for (int e = c.Qrow[m]; e < c.Qrow[m + 1]; ++e) acc += c.Qval[e] * lds_sp[c.Qcol[e]];
+                }
+                qs[k] = acc;
+            }
+        }
+    }
+    lds_barrier();                                     // ltab (and lds_sp reads done before it is rewritten)
     STAMP(1);
 
     // ---------------- phase 1: gradient at the current position ---------------
@@ -544,6 +565,31 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
                 w.ea[(size_t)b * d.Tp + t] = exp(acc);
                 w.rir[(size_t)b * d.Tp + t] = exp(ng0 + ng1 * wdt[k]);
             }
+            if (STAGE == 0 && d.chunked) {
+                // hand-over to the chunked leapfrog steps: a_t, and per 64-day chunk (= one wave here)
+                // the sums of alpha, v p and v alpha at the new position / momentum
+                if (t < T) w.acur[(size_t)b * d.Tp + t] = acc;
+                const double vv = (t >= 1 && t < T) ? va[k] : 0.0;
+                const double ca = wave_sum(v), cvp = wave_sum(vv * pa[k]), cva = wave_sum(vv * v);
+                const int chunk = (tid >> 6) + k * (HB / WAVE);
+                if ((tid & 63) == 0 && chunk < d.ntc) {
+                    double *ct = w.CT + (((size_t)b * 2 + 0) * CT_MAXC + chunk) * 4;
+                    ct[0] = ca; ct[1] = cvp; ct[2] = cva;
+                }
+            }
+        }
+        if (STAGE == 0 && d.chunked) {
+            // V(t) = sum_{s=1..t} var[alpha_t[s-1]]: constant over the trajectory
+            double vcarry = 0.0;
+#pragma unroll
+            for (int k = 0; k < HT; ++k) {
+                const int t = tid + k * HB;
+                const double vv = (t >= 1 && t < T) ? va[k] : 0.0;
+                double tot;
+                const double inc = vcarry + block_excl_scan_hb(vv, scn, tot) + vv;
+                vcarry += tot;
+                if (t < d.Tp) w.Vt[(size_t)b * d.Tp + t] = inc;
+            }
         }
     }
 #pragma unroll
@@ -551,6 +597,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         const int m = tid + k * HB;
         if (m < M) {
             w.eb[(size_t)b * d.Mp + m] = exp(nbeta * lam[k] + nsig * qm[k]) * inN[k];
+            if (w.sp != nullptr) w.sp[((size_t)b * 2 + 0) * d.Mp + m] = qm[k];     // buffer 0: see k_hmc_chunk
             double acc = 0.0;
             if (ell_pre) {
 #pragma unroll
@@ -591,6 +638,12 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         sc[SC_S0] = bc[10]; sc[SC_S1] = bc[11];
         sc[SC_PRIOR] = lp;
         sc[SC_JAC] = bc[8] + bc[9];
+        if (STAGE == 0 && d.chunked) {
+            double *g = w.gst + ((size_t)b * 2 + 0) * GST_N;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { g[i] = q6[i]; g[6 + i] = p6[i]; }
+            g[12] = npsi; g[13] = nsig; g[14] = bc[10]; g[15] = bc[11];
+        }
     }
     STAMP(9);
     if (STAGE == 2) {
@@ -607,6 +660,238 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
 #pragma unroll
                 for (int i = 2; i < 6; ++i) tr[i] = q6[i];
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hmc_chunk: one inner leapfrog step (full kick at the current position, drift to the next,
+// tables of the next) split over independent single-wave workgroups instead of one workgroup
+// per chain.  grid (ntc + Mp/64, chains) x 64 threads:
+//   T-chunk c (blockIdx.x < ntc): days 64c..64c+63 -- alpha_t entries, a_t, exp(a_t), the I->R
+//     rate table; chunk 0 also integrates alpha_0, gamma0, gamma1.
+//   M-chunk c: rows 64c..64c+63 -- spatial effects, exp(beta l + sigma s)/N; chunk 0 also
+//     integrates psi, sigma_space, beta_area (unconstrained u0, u1).
+// What couples the chunks is carried by scalars, so no workgroup waits for another:
+//   * k_se's tile scalars (Work::TS): per (row tile, day chunk) sum_t col, sum_t col V(t),
+//     sum_m l_m row, sum_m s_m row.  With G(s) = sum_{tau >= s} col[tau] the alpha_t gradient is
+//     G(s) - alpha_s / 0.005^2, and for a whole chunk c'
+//         sum_{s in c'} v_s G(s) = [A(c') - V0(c') B(c')] + Vtot(c') sum_{c'' > c'} B(c'')
+//     (A, B = the tile scalars summed over row tiles, V = prefix sums of the mass-matrix
+//     variances, constant over a trajectory): a chunk gets the prefix of the NEW alpha over the
+//     chunks before it without seeing their entries.
+//   * per-chunk sums of alpha, v p, v alpha at the current position (Work::CT), written by each
+//     T-chunk for the next step, double-buffered by the step's parity `par` like the spatial
+//     effects (Work::sp, gathered for the CAR term) and the global parameters (Work::gst).
+// Arithmetic per entry is that of k_hmc_step<1>; sums are associated differently (~1e-16).
+// ---------------------------------------------------------------------------------------------
+// NTC: the number of 64-day chunks at compile time (0 = any, loops stay rolled).  The kernel is one
+// wave of straight-line code executed once, so its cost is its instruction count.
+template <int NTC>
+__global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par) {
+    __shared__ double2 ltab[LOGTAB_N];
+    constexpr int NC = NTC > 0 ? NTC : CT_MAXC;
+    const int T = d.T, M = d.M, nmt = d.nmt;
+    const int ntc = NTC > 0 ? NTC : d.ntc;
+    const int ntile = nmt * ntc;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (d.aff_nb > 0) xcd_affine(blockIdx.x, ntc + d.Mp / WAVE, d.aff_nb, by, bx);
+    const int b = d.b0 + by, lane = threadIdx.x;
+    double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp;
+    const double *var = ch.var + (size_t)b * d.Pp;
+    double *sc = w.scal + (size_t)b * NSCAL;
+    const double eps = ch.hs[(size_t)b * NHS + HS_EPS];
+    const int oT = 6 - 1, oM = 6 + T - 1;
+    const double *TS = w.TS + (size_t)b * ntile * 4;
+    const double *gr = w.gst + ((size_t)b * 2 + par) * GST_N;
+    double *gw = w.gst + ((size_t)b * 2 + (par ^ 1)) * GST_N;
+    if (bx < ntc) {
+        // ------------------------------------------------------------------ T-chunk
+        const int ci = bx, t = ci * WAVE + lane;
+        const bool own = t >= 1 && t < T;
+        ltab[lane] = c.logtab[lane];
+        ltab[lane + WAVE] = c.logtab[lane + WAVE];
+        const double alpha = own ? q[oT + t] : 0.0, pm = own ? p[oT + t] : 0.0, v = own ? var[oT + t] : 0.0;
+        const double wd_t = c.wd[t];
+        const double a0 = gr[5], g0 = gr[3], g1 = gr[4], pa0 = gr[11], pg0 = gr[9], pg1 = gr[10];
+        const double va0 = var[5], vg0 = var[3], vg1 = var[4];
+        // column sums of this chunk
+        double col = 0.0;
+        {
+            const double *kp = w.Kpart + (size_t)b * nmt * d.Tp + t;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+            for (int j0 = 0; j0 < nmt; j0 += 24) {
+                double x[24];
+#pragma unroll
+                for (int j = 0; j < 24; ++j) x[j] = j0 + j < nmt ? kp[(size_t)(j0 + j) * d.Tp] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 24; j += 4) { c0 += x[j]; c1 += x[j + 1]; c2 += x[j + 2]; c3 += x[j + 3]; }
+            }
+            col = (c0 + c1) + (c2 + c3);
+        }
+        // tile scalars of row tile `lane` (and lane+64, ... when there are more), V at the chunk ends,
+        // the chunk sums of the current position (chunk = lane)
+        double bs[NC], as[NC], vend[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const bool on = cc < ntc && lane < nmt;
+            bs[cc] = on ? TS[((size_t)lane * ntc + cc) * 4] : 0.0;
+            as[cc] = on ? TS[((size_t)lane * ntc + cc) * 4 + 1] : 0.0;
+            vend[cc] = cc < ntc ? w.Vt[(size_t)b * d.Tp + cc * WAVE + WAVE - 1] : 0.0;
+        }
+        for (int r = lane + WAVE; r < nmt; r += WAVE)
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+                if (cc < ntc) { bs[cc] += TS[((size_t)r * ntc + cc) * 4]; as[cc] += TS[((size_t)r * ntc + cc) * 4 + 1]; }
+        const double *ctr = w.CT + (((size_t)b * 2 + par) * CT_MAXC) * 4;
+        const double cta_l = lane < ntc ? ctr[lane * 4] : 0.0, ctvp_l = lane < ntc ? ctr[lane * 4 + 1] : 0.0,
+                     ctva_l = lane < ntc ? ctr[lane * 4 + 2] : 0.0;
+        // I->R gradient (gamma0, gamma1): every T-chunk sums all days, they are few
+        double kirv[NC], dirv[NC], ratev[NC], wdv[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int tt = j * WAVE + lane;
+            const bool on = j < ntc && tt < T;
+            kirv[j] = on ? w.Kir[(size_t)b * d.Tp + tt] : 0.0;
+            dirv[j] = on ? w.Dir[(size_t)b * d.Tp + tt] : 0.0;
+            ratev[j] = on ? w.rir[(size_t)b * d.Tp + tt] : 1.0;
+            wdv[j] = on ? c.wd[tt] : 0.0;
+        }
+        lds_barrier();                                     // ltab (single wave: orders the LDS writes)
+        double gg0 = 0.0, gg1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int tt = j * WAVE + lane;
+            if (j < ntc && tt < T) {
+                double L, inv;
+                l1me_inv(ratev[j] * d.dt, L, inv, ltab);
+                const double grr = d.dt * ((kirv[j] != 0.0 ? kirv[j] * inv : 0.0) - dirv[j]);
+                gg0 += grr * ratev[j];
+                gg1 += grr * ratev[j] * wdv[j];
+            }
+        }
+        gg0 = wave_sum(gg0);
+        gg1 = wave_sum(gg1);
+        // Everything that couples the chunks is linear in the tile scalars, so each lane forms its
+        // row tile's share and three wave sums finish the job:
+        //   later = sum_{c' > ci} B(c'),  allB = sum B,
+        //   pre   = sum_{c' < ci} [new alpha summed over chunk c']
+        //         = sum_{c' < ci} { CTa + eps (CTvp + eps [ (A - V0 B) + Vtot sum_{c''>c'} B - CTva / 0.005^2 ]) }
+        constexpr double PREC = 1.0 / (0.005 * 0.005);
+        double p_later = 0.0, p_all = 0.0, p_pre = 0.0, lat = 0.0;
+#pragma unroll
+        for (int cc = NC - 1; cc >= 0; --cc) {
+            if (cc >= ntc) continue;
+            const double V0 = cc > 0 ? vend[cc > 0 ? cc - 1 : 0] : 0.0, V1 = vend[cc];
+            if (cc < ci) p_pre += (as[cc] - V0 * bs[cc]) + (V1 - V0) * lat;
+            if (cc > ci) p_later += bs[cc];
+            p_all += bs[cc];
+            lat += bs[cc];
+        }
+        p_pre = eps * eps * p_pre + (lane < ci ? cta_l + eps * (ctvp_l - eps * PREC * ctva_l) : 0.0);
+        const double later = wave_sum(p_later), allB = wave_sum(p_all), pre = wave_sum(p_pre);
+        // this chunk's entries
+        const double insuf = wave_incl_suffix_scan(col, lane);
+        const double g = own ? (insuf + later) - alpha * PREC : 0.0;
+        const double pn = own ? pm + eps * g : 0.0;
+        const double an = own ? alpha + eps * v * pn : 0.0;
+        const double pa0n = pa0 + eps * (allB - a0 / 100.0), a0n = a0 + eps * va0 * pa0n;
+        const double pg0n = pg0 + eps * (gg0 - g0 / 1.0e4), g0n = g0 + eps * vg0 * pg0n;
+        const double pg1n = pg1 + eps * (gg1 - g1 / 1.0e4), g1n = g1 + eps * vg1 * pg1n;
+        const double a_new = a0n + pre + wave_incl_scan(an, lane);
+        if (own) { q[oT + t] = an; p[oT + t] = pn; }
+        if (t < T) {
+            w.acur[(size_t)b * d.Tp + t] = a_new;
+            w.ea[(size_t)b * d.Tp + t] = exp(a_new);
+            w.rir[(size_t)b * d.Tp + t] = exp(g0n + g1n * wd_t);
+        }
+        const double ca = wave_sum(an), cvp = wave_sum(v * pn), cva = wave_sum(v * an);
+        if (lane == 0) {
+            double *ctw = w.CT + (((size_t)b * 2 + (par ^ 1)) * CT_MAXC + ci) * 4;
+            ctw[0] = ca; ctw[1] = cvp; ctw[2] = cva;
+            if (ci == 0) {
+                q[3] = g0n; q[4] = g1n; q[5] = a0n; p[3] = pg0n; p[4] = pg1n; p[5] = pa0n;
+                gw[3] = g0n; gw[4] = g1n; gw[5] = a0n; gw[9] = pg0n; gw[10] = pg1n; gw[11] = pa0n;
+                sc[SC_G0] = g0n; sc[SC_G1] = g1n; sc[SC_A0] = a0n;
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ M-chunk
+        const int ci = bx - ntc, m = ci * WAVE + lane;
+        const bool own = m < M;
+        const double *spr = w.sp + ((size_t)b * 2 + par) * d.Mp;
+        double *spw = w.sp + ((size_t)b * 2 + (par ^ 1)) * d.Mp;
+        const double sm = own ? q[oM + m] : 0.0, pm = own ? p[oM + m] : 0.0, v = own ? var[oM + m] : 0.0;
+        const double lm = own ? c.la[m] : 0.0, inN = own ? c.invN[m] : 0.0;
+        const double u0 = gr[0], u1 = gr[1], beta = gr[2], p0 = gr[6], p1 = gr[7], p2 = gr[8];
+        const double psi = gr[12], sig = gr[13], s0 = gr[14], s1 = gr[15];
+        const double v0 = var[0], v1 = var[1], v2 = var[2];
+        double R = 0.0;
+        {
+            const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (own ? m : 0);
+            double x[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) x[j] = (own && j < ntc) ? rp[(size_t)j * d.Mp] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) R += x[j];
+        }
+        double Qs = 0.0;                                   // (Q s)_m at the current position
+        if (own) {
+            if (c.qw > 0 && c.qw <= 8) {
+                double qv[8]; int qc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool on = j < c.qw;
+                    qv[j] = on ? c.Qell_val[(size_t)j * d.Mp + m] : 0.0;
+                    qc[j] = on ? c.Qell_col[(size_t)j * d.Mp + m] : 0;
+                }
+                double sv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sv[j] = spr[qc[j]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Qs += qv[j] * sv[j];
+            } else {
+                for (int e = c.Qrow[m]; e < c.Qrow[m + 1]; ++e) Qs += c.Qval[e] * spr[c.Qcol[e]];
+            }
+        }
+        double ps = 0.0, rl = 0.0, rs = 0.0;
+        for (int i0 = lane; i0 < ntile; i0 += 4 * WAVE) {
+            double x[4], y[4], z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * WAVE;
+                const bool on = i < ntile;
+                x[j] = on ? w.Ppart[(size_t)b * ntile + i] : 0.0;
+                y[j] = on ? TS[(size_t)i * 4 + 2] : 0.0;
+                z[j] = on ? TS[(size_t)i * 4 + 3] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ps += x[j]; rl += y[j]; rs += z[j]; }
+        }
+        ps = wave_sum(ps); rl = wave_sum(rl); rs = wave_sum(rs);
+        const double g = own ? sig * R - Qs : 0.0;
+        const double pn = pm + eps * g;
+        const double sn = sm + eps * v * pn;
+        const double p0n = p0 + eps * ((ps + 2.0 / psi - 10.0) * s0 + (1.0 - s0)), u0n = u0 + eps * v0 * p0n;
+        const double p1n = p1 + eps * ((rs - sig / 0.01) * s1 + (1.0 - s1)), u1n = u1 + eps * v1 * p1n;
+        const double p2n = p2 + eps * (rl - beta), betan = beta + eps * v2 * p2n;
+        // both softplus in one pass: lane 0 takes u0, the other lanes u1
+        const double e0 = 2.220446049250313e-16;
+        const double ux = lane == 0 ? u0n : u1n;
+        const double spx = softplus(ux);
+        const double sgx = cold_exp(ux - spx);             // sigmoid(u) = exp(u - softplus(u))
+        const double psin = lane_value(spx, 0) + e0, sign = lane_value(spx, 1) + e0;
+        const double s0n = lane_value(sgx, 0), s1n = lane_value(sgx, 1);
+        if (own) {
+            q[oM + m] = sn; p[oM + m] = pn;
+            spw[m] = sn;
+            w.eb[(size_t)b * d.Mp + m] = exp(betan * lm + sign * sn) * inN;
+        }
+        if (ci == 0 && lane == 0) {
+            q[0] = u0n; q[1] = u1n; q[2] = betan; p[0] = p0n; p[1] = p1n; p[2] = p2n;
+            gw[0] = u0n; gw[1] = u1n; gw[2] = betan; gw[6] = p0n; gw[7] = p1n; gw[8] = p2n;
+            gw[12] = psin; gw[13] = sign; gw[14] = s0n; gw[15] = s1n;
+            sc[SC_PSI] = psin; sc[SC_SIG] = sign; sc[SC_BETA] = betan; sc[SC_S0] = s0n; sc[SC_S1] = s1n;
         }
     }
 }

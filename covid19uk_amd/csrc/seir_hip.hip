@@ -620,6 +620,7 @@ struct seir_sampler {
     std::vector<hipEvent_t> ev_join;
     bool use_graph = true;
     bool legacy_moves = false;    // SEIR_MOVES=legacy: first implementation of the proposal kernel (k_move_pa)
+    bool hmc_chunked = true;      // SEIR_HMC=single: every leapfrog step by the single-workgroup kernel
     int moves_mode = 0;           // 0 = paired launches (k_move_pair); 1 = one proposal kernel per update (split / legacy)
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
@@ -653,6 +654,7 @@ extern "C" void seir_sampler_destroy(seir_sampler *s) {
     Work &w = s->ctx->w;
     for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
     w.rowtot = nullptr;
+    w.TS = w.sp = w.gst = w.Vt = w.acur = w.CT = nullptr;
     delete s;
 }
 
@@ -695,6 +697,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         s->use_graph = e && atoi(e) != 0 && getenv("SEIR_NO_GRAPH") == nullptr;
     }
     {
+        const char *h = getenv("SEIR_HMC");
+        s->hmc_chunked = !(h && strcmp(h, "single") == 0);
         // SEIR_MOVES: (default) paired launches | "split": k_move_pa2 per update | "legacy": k_move_pa per update
         const char *e = getenv("SEIR_MOVES");
         s->legacy_moves = e && strcmp(e, "legacy") == 0;
@@ -717,6 +721,12 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
 #define S_ALLOC(ptr, n) if (!rc) rc = s_alloc(s, &(ptr), (n))
     for (int x = 0; x < 3; ++x) { S_ALLOC(w.K[x], cells); S_ALLOC(w.St[x], cells); }
     S_ALLOC(w.rowtot, (size_t)ctx->Bmax * 2 * d.Mp);
+    S_ALLOC(w.TS, (size_t)ctx->Bmax * d.nmt * d.ntc * 4);
+    S_ALLOC(w.sp, (size_t)ctx->Bmax * 2 * d.Mp);
+    S_ALLOC(w.gst, (size_t)ctx->Bmax * 2 * GST_N);
+    S_ALLOC(w.Vt, (size_t)ctx->Bmax * d.Tp);
+    S_ALLOC(w.acur, (size_t)ctx->Bmax * d.Tp);
+    S_ALLOC(w.CT, (size_t)ctx->Bmax * 2 * CT_MAXC * 4);
     S_ALLOC(ch.q, (size_t)B * d.Pp); S_ALLOC(ch.p, (size_t)B * d.Pp); S_ALLOC(ch.q0, (size_t)B * d.Pp);
     S_ALLOC(ch.grad, (size_t)B * d.Pp); S_ALLOC(ch.var, (size_t)B * d.Pp);
     S_ALLOC(ch.rv_mean, (size_t)B * d.Pp); S_ALLOC(ch.rv_m2, (size_t)B * d.Pp);
@@ -923,26 +933,28 @@ extern "C" int seir_sampler_reset_trace(seir_sampler *s) {
 }
 
 template <int HT, int HM>
-static void launch_hmc_t(seir_ctx *ctx, const LaunchCfg &l, const SamplerCfg &c, const Chains &ch, int stage) {
+static void launch_hmc_t(seir_ctx *ctx, const LaunchCfg &l, const SamplerCfg &c, const Chains &ch, int stage,
+                         int gather_qs) {
     const size_t lds = (size_t)l.d.Mp * sizeof(double);
     const dim3 g(l.nb), blk(HB);
     if (stage == 0)
-        hipLaunchKernelGGL((k_hmc_step<0, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch);
+        hipLaunchKernelGGL((k_hmc_step<0, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch, gather_qs);
     else if (stage == 1)
-        hipLaunchKernelGGL((k_hmc_step<1, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch);
+        hipLaunchKernelGGL((k_hmc_step<1, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch, gather_qs);
     else
-        hipLaunchKernelGGL((k_hmc_step<2, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch);
+        hipLaunchKernelGGL((k_hmc_step<2, HT, HM>), g, blk, lds, l.st, l.d, ctx->c, ctx->w, c, ch, gather_qs);
 }
-static void launch_hmc(seir_ctx *ctx, const LaunchCfg &l, const SamplerCfg &c, const Chains &ch, int stage) {
+static void launch_hmc(seir_ctx *ctx, const LaunchCfg &l, const SamplerCfg &c, const Chains &ch, int stage,
+                       int gather_qs = 0) {
     const int ht = (l.d.Tp + HB - 1) / HB, hm = (l.d.M + HB - 1) / HB;    // sampler_create caps T<=1024, M<=2048
     if (ht <= 1) {
-        if (hm <= 1) launch_hmc_t<1, 1>(ctx, l, c, ch, stage);
-        else if (hm <= 2) launch_hmc_t<1, 2>(ctx, l, c, ch, stage);
-        else launch_hmc_t<1, 4>(ctx, l, c, ch, stage);
+        if (hm <= 1) launch_hmc_t<1, 1>(ctx, l, c, ch, stage, gather_qs);
+        else if (hm <= 2) launch_hmc_t<1, 2>(ctx, l, c, ch, stage, gather_qs);
+        else launch_hmc_t<1, 4>(ctx, l, c, ch, stage, gather_qs);
     } else {
-        if (hm <= 1) launch_hmc_t<2, 1>(ctx, l, c, ch, stage);
-        else if (hm <= 2) launch_hmc_t<2, 2>(ctx, l, c, ch, stage);
-        else launch_hmc_t<2, 4>(ctx, l, c, ch, stage);
+        if (hm <= 1) launch_hmc_t<2, 1>(ctx, l, c, ch, stage, gather_qs);
+        else if (hm <= 2) launch_hmc_t<2, 2>(ctx, l, c, ch, stage, gather_qs);
+        else launch_hmc_t<2, 4>(ctx, l, c, ch, stage, gather_qs);
     }
 }
 
@@ -960,13 +972,42 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     group_range(s, g, b0, nb);
     LaunchCfg l{ctx->d, s->gstream[g], nb, affinity_enabled()};
     l.d.b0 = b0;
+    const Dims d0 = l.d;
     hipStream_t st = l.st;
     // [part 0] HMC on u | events: L+1 gradient evaluations
+    const bool chunked = s->hmc_chunked && c.L >= 3 && d0.ntc <= CT_MAXC;
+    l.d.chunked = chunked ? 1 : 0;
+    l.d.sp_par = 0;
     launch_se<1>(ctx, l, true);
     launch_hmc(ctx, l, c, s->ch, 0);
-    for (int i = 1; i < c.L; ++i) {
+    if (!chunked) {
+        for (int i = 1; i < c.L; ++i) {
+            launch_se<1>(ctx, l, true);
+            launch_hmc(ctx, l, c, s->ch, 1);
+        }
+    } else {
+        // inner steps 1..L-2 by independent 64-lane chunks (k_hmc_chunk), the last inner step by the
+        // single-workgroup kernel, which leaves (Q s), priors and Jacobian of the end point for stage 2
+        const int per = d0.ntc + d0.Mp / WAVE;
+        const bool aff = (l.affinity & 1) && xcd_affinity_applies(per, nb);
+        int par = 0;
+        for (int i = 1; i < c.L - 1; ++i) {
+            l.d.sp_par = par;
+            launch_se<1>(ctx, l, true);
+            Dims dc = l.d;
+            dc.aff_nb = aff ? nb : 0;
+            const dim3 gc = aff ? dim3(per * nb) : dim3(per, nb);
+            switch (d0.ntc) {       // chunk count at compile time for the BASELINE sizes (NI, UK, SYN), rolled loops otherwise
+                case 1: hipLaunchKernelGGL(k_hmc_chunk<1>, gc, dim3(WAVE), 0, st, dc, ctx->c, ctx->w, c, s->ch, par); break;
+                case 6: hipLaunchKernelGGL(k_hmc_chunk<6>, gc, dim3(WAVE), 0, st, dc, ctx->c, ctx->w, c, s->ch, par); break;
+                case 12: hipLaunchKernelGGL(k_hmc_chunk<12>, gc, dim3(WAVE), 0, st, dc, ctx->c, ctx->w, c, s->ch, par); break;
+                default: hipLaunchKernelGGL(k_hmc_chunk<0>, gc, dim3(WAVE), 0, st, dc, ctx->c, ctx->w, c, s->ch, par); break;
+            }
+            par ^= 1;
+        }
+        l.d.sp_par = par;
         launch_se<1>(ctx, l, true);
-        launch_hmc(ctx, l, c, s->ch, 1);
+        launch_hmc(ctx, l, c, s->ch, 1, /*gather_qs=*/1);
     }
     launch_se<1>(ctx, l, true);
     launch_hmc(ctx, l, c, s->ch, 2);
@@ -1096,9 +1137,11 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
     if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
     if (!mean_ms || iters < 1) return fail(SEIR_ERR_INVALID, "bad iters/mean_ms");
     seir_ctx *ctx = s->ctx;
-    launch_se<1>(ctx, whole(ctx, s->cfg.B), true);
+    LaunchCfg l = whole(ctx, s->cfg.B);
+    l.d.chunked = (s->hmc_chunked && s->cfg.L >= 3 && l.d.ntc <= CT_MAXC) ? 1 : 0;   // the kernel as the sweep runs it
+    launch_se<1>(ctx, l, true);
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < iters; ++i) launch_se<1>(ctx, whole(ctx, s->cfg.B), true);
+    for (int i = 0; i < iters; ++i) launch_se<1>(ctx, l, true);
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;

@@ -55,7 +55,7 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
             assert np.max(np.abs(trace.theta[i, b] - o["theta"]) / scale) < theta_rtol, (i, b, "theta")
 
 
-@pytest.mark.parametrize("moves", ["default", "split", "legacy"])
+@pytest.mark.parametrize("moves", ["default", "split", "legacy", "default+single"])
 @pytest.mark.parametrize("name,cfg,seed,eps,n", [
     ("micro_5x24", CFG_SMALL, 1, 0.002, 12),
     ("ni11", CFG_REF, 2, 0.002, 8),
@@ -69,7 +69,9 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
 def test_fixed_kernel_sweeps_match_oracle(api, monkeypatch, name, cfg, seed, eps, n, moves):
     """The three forms of the event-update launches -- paired (k_move_pair, default), one proposal
     kernel per update (k_move_pa2) and the first implementation (k_move_pa) -- against the oracle."""
-    monkeypatch.setenv("SEIR_MOVES", moves)
+    # "+single": every leapfrog step by the single-workgroup kernel instead of the 64-lane chunks
+    monkeypatch.setenv("SEIR_MOVES", moves.split("+")[0])
+    monkeypatch.setenv("SEIR_HMC", "single" if moves.endswith("+single") else "chunk")
     SeirModel, ChainSampler = api
     case = H.build_case(name, seed, alpha_t_sd=0.005)
     B = 2
