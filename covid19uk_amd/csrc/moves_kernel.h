@@ -633,14 +633,14 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
 // updated rows, accept test, state update, trace -- is local to the workgroup that proposes it.
 // Only the E->I updates need the chip (F moves on a band of days for every row).  The launch
 // therefore does, in order:
-//   (1) every block: finalize the pending E->I-type proposal (accept test from k_move_delta's
-//       partial sums; F band update by all blocks; rows, trace by block 0)      [as k_move_pa2]
+//   (1) finalize the pending E->I-type proposal: accept test from k_move_delta's partial sums, rows,
+//       trace; its F band is left to the next k_move_delta / k_apply_fpend (Chains::fpend)
 //   (2) block 0: the complete S->E-type update `se`
 //   (3) block 0: draw the E->I-type proposal `next` for the following k_move_delta
 // which takes a scan from 8 launches to 4.  se.kind < 0: no S->E update; next.kind == -2: closing
 // launch of the sweep (advance the counter).  Random streams, proposal arithmetic and the order
 // of the four updates are those of k_move_pa2 / the oracle.
-// grid (nrb_d, B) or its XCD-affine 1-D form, MVB threads.
+// grid (B), MVB threads: one workgroup per chain.
 // ---------------------------------------------------------------------------------------------
 constexpr int PRE_RT = 4;                                      // prefetched rows per thread (M <= 2048)
 
@@ -749,9 +749,9 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     __shared__ double2 ltab[LDSTAB_N];
     __shared__ int s_acc, s_acc_se;
     __shared__ double s_dth, s_dcn;
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
-    const int b = d.b0 + by, tid = threadIdx.x;
+    // one workgroup per chain: block id = chain keeps the chain <-> XCD affinity of the other kernels
+    const int bx = 0;
+    const int b = d.b0 + blockIdx.x, tid = threadIdx.x;
     const int M = d.M, T = d.T;
     const bool do_se = bx == 0 && se.kind >= 0, do_nx = bx == 0 && next.kind >= 0;
 #ifdef SEIR_STAMPS
@@ -784,6 +784,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     }
     // ---- (1) finalize the pending E->I-type proposal
     bool pend_acc = false;
+    if (!have_prev && tid == 64) ch.fpend[b].valid = 0;   // first launch of a sweep: nothing pending
     if (have_prev) {
         if (tid == 0) pend = ch.mv[(size_t)pbuf * s.B + b];
         double dth = 0.0, dcn = 0.0;
@@ -800,26 +801,13 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         __syncthreads();
         pend_acc = s_acc != 0;
         const Move &mv = pend;
-        if (pend_acc && mv.any_dI) {
-            // F[j][t] += sum_i Cstar[j][m_i] dI_i / N_{m_i}  on each update's day window
-            const int rows_per_blk = (M + s.nrb_d - 1) / s.nrb_d;
-            const int r_lo = bx * rows_per_blk, r_hi = min(M, r_lo + rows_per_blk);
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int j = r_lo + wave; j < r_hi; j += MVW) {
-                double coef[MMAX];
-#pragma unroll
-                for (int i = 0; i < MMAX; ++i)
-                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
-                                       : 0.0;
-                double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
-                for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
-                    double dF = 0.0;
-#pragma unroll
-                    for (int i = 0; i < MMAX; ++i)
-                        if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
-                    if (dF != 0.0) Fr[t] += dF;
-                }
-            }
+        // The F band of an accepted E->I update is NOT written here: k_move_delta (or k_apply_fpend at the
+        // end of the sweep) does it with the whole chip; the S->E update below adds the pending band to
+        // the F values it reads.
+        if (tid == 64) {
+            Move *fp = ch.fpend + b;
+            if (pend_acc && mv.any_dI) { *fp = mv; fp->valid = 1; }
+            else fp->valid = 0;
         }
         if (bx == 0) {
             if (pend_acc) mv_apply_rows(d, w, b, mv);
@@ -853,7 +841,8 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         PSTAMP(3);
         const Move &mv = sm_se.mv;
         double dth = 0.0, dcn = 0.0;
-        if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, M, ltab, dth, dcn);
+        const Move *fpp = (have_prev && pend_acc && pend.any_dI) ? &pend : nullptr;
+        if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, M, ltab, dth, dcn, fpp);
         PSTAMP(4);
         mv_sum2(dth, dcn, sm_se.dred);
         if (tid == 0) {

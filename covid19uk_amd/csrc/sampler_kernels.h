@@ -68,6 +68,7 @@ struct Chains {
     double *q, *p, *q0, *grad, *var, *rv_mean, *rv_m2;   // [B][Pp]
     double *hs;                                          // [B][NHS]
     Move *mv;                                            // [2][B] double-buffered proposal descriptors
+    Move *fpend;                                         // [B] accepted E->I-type update whose F band is still to be applied (valid = 1)
     double *Dpart;                                       // [B][nrb_d][2]
     unsigned *sweep;                                     // [B] sweeps done (device resident: graph replays advance it)
     unsigned *slot0;                                     // [1] sweep index of trace slot 0
@@ -1161,10 +1162,12 @@ __device__ inline void cell_terms(const Dims &d, double S, double E, double I, d
 // for E->I updates F moves as well): sum over the touched days of [terms(new) - terms(old)].
 // Rows outside [r_lo, r_hi) are skipped (k_move_delta: the block that owns the row; the fused
 // S->E kernel passes the whole range).  NT threads of the calling block take part.
+// fp != nullptr: an accepted E->I update whose F band has not been written yet (see Chains::fpend);
+// its contribution is added to the F values read here.
 template <int NT>
 __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, const Work &w, int b, const Move &mv,
                                                double psi, int r_lo, int r_hi, const double2 *ltab, double &dth,
-                                               double &dcn) {
+                                               double &dcn, const Move *fp = nullptr) {
     const double r_ei = d.nu * d.dt, L_ei = d.L_ei;
     const double *ea = w.ea + (size_t)b * d.Tp;
     for (int i0 = 0; i0 < mv.n; ++i0) {
@@ -1178,6 +1181,11 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
             coef[i] = (i < mv.n && mv.tgt == 1)
                           ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
                           : 0.0;
+        double cfp[MMAX];
+#pragma unroll
+        for (int i = 0; i < MMAX; ++i)
+            cfp[i] = (fp && i < fp->n) ? c.Cstar[(size_t)fp->m[i] * d.Kp0 + j] * c.invN[fp->m[i]] * (double)(-fp->dsrc[i])
+                                       : 0.0;
         for (int t = mv.LO + (int)threadIdx.x; t <= mv.HI; t += NT) {
             double dF = 0.0;
 #pragma unroll
@@ -1195,7 +1203,12 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
             const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
             const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
             const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
-            const double F = w.F[rowoff + t];
+            double F = w.F[rowoff + t];
+            if (fp) {
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < fp->n && t > fp->lo[i] && t <= fp->hi[i]) F += cfp[i];
+            }
             const double ee = ea[t] * eb, psiW = psi * c.W[t];
             const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
             const double L_ir = log1mexp(r_ir, ltab);
@@ -1207,6 +1220,42 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
             dcn += cn1 - cn0;
         }
     }
+}
+
+// F[j][t] += sum_i Cstar[j][m_i] dI_i / N_{m_i} on each update's day window, rows [r_lo, r_hi),
+// one wave per row (NW waves in the calling block)
+template <int NW>
+__device__ __forceinline__ void apply_f_band(const Dims &d, const Consts &c, const Work &w, int b, const Move &mv,
+                                             int r_lo, int r_hi) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = r_lo + wave; j < r_hi; j += NW) {
+        double coef[MMAX];
+#pragma unroll
+        for (int i = 0; i < MMAX; ++i)
+            coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i]) : 0.0;
+        double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
+        for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
+            double dF = 0.0;
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+            if (dF != 0.0) Fr[t] += dF;
+        }
+    }
+}
+
+// End of a sweep in the paired form: the F band of the last accepted E->I update (k_move_delta applies
+// the others on its way in).  grid (nrb_d, B).
+__global__ __launch_bounds__(256) void k_apply_fpend(Dims d, Consts c, Work w, SamplerCfg s, Chains ch) {
+    __shared__ Move fp;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
+    const int b = d.b0 + by;
+    if (threadIdx.x == 0) fp = ch.fpend[b];
+    __syncthreads();
+    if (fp.valid != 1) return;
+    const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
+    apply_f_band<4>(d, c, w, b, fp, bx * rows_per_blk, min(d.M, (bx + 1) * rows_per_blk));
 }
 
 // Change of the S->E term of a cell whose F moves by dF while its own state is unchanged:
@@ -1244,8 +1293,12 @@ __device__ __forceinline__ double band_delta(double S, double I, double K0, doub
 // grid (nrb_d, B).  Rows that only see a changed F (E->I moves): one wave per row, lanes
 // over the days of the hull.  The (<= m) rows whose own state changes carry the expensive
 // binomial-coefficient terms, so the whole workgroup spreads over that row's days.
-__global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf) {
+// apply_f != 0 (paired form): the block first writes the F band of the previously accepted E->I update
+// (Chains::fpend) for its own rows -- the only rows whose F it reads below.
+__global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf,
+                                                    int apply_f) {
     __shared__ Move mv;
+    __shared__ Move fp;
     __shared__ double sh_th[4], sh_cn[4];
     __shared__ double2 ltab[LDSTAB_N];
     int bx = blockIdx.x, by = blockIdx.y;
@@ -1266,7 +1319,13 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
 #endif
     DSTAMP(0);
     if (threadIdx.x == 0) mv = ch.mv[(size_t)buf * s.B + b];
+    if (apply_f && threadIdx.x == 64) fp = ch.fpend[b];
     log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes mv
+    if (apply_f && fp.valid == 1) {
+        const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
+        apply_f_band<4>(d, c, w, b, fp, bx * rows_per_blk, min(d.M, (bx + 1) * rows_per_blk));
+        __syncthreads();                           // the band written above is read below
+    }
 #ifdef SEIR_STAMPS
     dstamp_on = mv.slot == SEIR_STAMP_SLOT;
 #endif
