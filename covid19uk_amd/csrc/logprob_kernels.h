@@ -34,7 +34,8 @@ struct Dims {
     int b0;                 // first chain handled by this launch (chain groups on separate streams)
     int nrb_scan;           // row blocks of k_scan
     int nmt, ntc;           // k_se tiles: Mp/SE_TM row tiles, Tp/64 day chunks
-    int chunked;            // sampler: k_se also writes the tile scalars of the chunked leapfrog (Work::TS)
+    int chunked;            // sampler: k_se also writes the tile scalars of the chunked leapfrog (Work::TS):
+                            // 1 = column scalars only (the M-chunks sum the row partials themselves), 2 = all four
     int sp_par;             // which of the two Work::sp / Work::gst buffers holds the current position
     int aff_nb;             // 0 = natural grids (tile, chain); > 0 = 1-D grids of tiles*aff_nb blocks with chain <-> XCD affinity
     double nu, dt, rate_floor, car_half_logdet;
@@ -442,13 +443,14 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     }
     // tile scalars for the chunked leapfrog: operands fetched with the other loads
     const bool ts_on = GRAD && SRC == 1 && d.chunked != 0;
+    const bool ts_rows = GRAD && SRC == 1 && d.chunked == 2;
     double ts_vt = 0.0, ts_l[SE_RW], ts_s[SE_RW];
     // the wave's rows are the same for all its lanes: scalar loads, the values live in SGPRs
     const int m0u = by * SE_TM + __builtin_amdgcn_readfirstlane(wave) * SE_RW;
 #pragma unroll
     for (int r = 0; r < SE_RW; ++r) {
-        ts_l[r] = ts_on ? c.la[m0u + r] : 0.0;
-        ts_s[r] = ts_on ? w.sp[((size_t)b * 2 + d.sp_par) * d.Mp + m0u + r] : 0.0;
+        ts_l[r] = ts_rows ? c.la[m0u + r] : 0.0;
+        ts_s[r] = ts_rows ? w.sp[((size_t)b * 2 + d.sp_par) * d.Mp + m0u + r] : 0.0;
     }
     if (ts_on) ts_vt = w.Vt[(size_t)b * d.Tp + t];
     __syncthreads();
@@ -468,8 +470,10 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
             const double ge = gl * lam0;
             myrow[r * SE_RS + lane] = ge;
             colacc += ge;
-            rlacc = fma(ge, ts_l[r], rlacc);              // sum_m l_m (row sum)_m and sum_m s_m (row sum)_m, cell by cell
-            rsacc = fma(ge, ts_s[r], rsacc);
+            if (ts_rows) {                                // uniform
+                rlacc = fma(ge, ts_l[r], rlacc);          // sum_m l_m (row sum)_m and sum_m s_m (row sum)_m, cell by cell
+                rsacc = fma(ge, ts_s[r], rsacc);
+            }
             gpsi += gl * ee * Wt * F[r];
         }
     }
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, WAVE);
         if (ss == 0) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + m0 + rr_] = v;
-        if (ts_on) { rlbuf[wave][lane] = rlacc; rsbuf[wave][lane] = rsacc; }
+        if (ts_rows) { rlbuf[wave][lane] = rlacc; rsbuf[wave][lane] = rsacc; }
     }
     __syncthreads();
     const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
             if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
         }
     } else if (GRAD && wave == 3) {
-        if (ts_on) {
+        if (ts_rows) {
             const double rl = wave_sum((rlbuf[0][lane] + rlbuf[1][lane]) + (rlbuf[2][lane] + rlbuf[3][lane]));
             const double rs = wave_sum((rsbuf[0][lane] + rsbuf[1][lane]) + (rsbuf[2][lane] + rsbuf[3][lane]));
             if (lane == 0) { w.TS[tile * 4 + 2] = rl; w.TS[tile * 4 + 3] = rs; }

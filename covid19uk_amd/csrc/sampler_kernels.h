@@ -856,6 +856,7 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
             }
         }
         double ps = 0.0, rl = 0.0, rs = 0.0;
+        const bool rows_here = d.chunked == 1;             // small M: sum_m l_m R_m, sum_m s_m R_m from the row partials
         for (int i0 = lane; i0 < ntile; i0 += 4 * WAVE) {
             double x[4], y[4], z[4];
 #pragma unroll
@@ -863,11 +864,35 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
                 const int i = i0 + j * WAVE;
                 const bool on = i < ntile;
                 x[j] = on ? w.Ppart[(size_t)b * ntile + i] : 0.0;
-                y[j] = on ? TS[(size_t)i * 4 + 2] : 0.0;
-                z[j] = on ? TS[(size_t)i * 4 + 3] : 0.0;
+                y[j] = (on && !rows_here) ? TS[(size_t)i * 4 + 2] : 0.0;
+                z[j] = (on && !rows_here) ? TS[(size_t)i * 4 + 3] : 0.0;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ps += x[j]; rl += y[j]; rs += z[j]; }
+        }
+        if (rows_here) {
+            // Mp <= 512: rows lane, lane+64, ...: ntc partials each, one batch of loads
+            constexpr int RPL = 8;
+            double la_[RPL], sp_[RPL], Rr[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                const int mm = lane + k * WAVE;
+                const bool on = mm < M;
+                la_[k] = on ? c.la[mm] : 0.0;
+                sp_[k] = on ? spr[mm] : 0.0;
+                double acc = 0.0;
+                if (on) {
+                    const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + mm;
+                    double x[NC];
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) x[j] = j < ntc ? rp[(size_t)j * d.Mp] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) acc += x[j];
+                }
+                Rr[k] = acc;
+            }
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) { rl = fma(la_[k], Rr[k], rl); rs = fma(sp_[k], Rr[k], rs); }
         }
         ps = wave_sum(ps); rl = wave_sum(rl); rs = wave_sum(rs);
         const double g = own ? sig * R - Qs : 0.0;

@@ -977,7 +977,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     hipStream_t st = l.st;
     // [part 0] HMC on u | events: L+1 gradient evaluations
     const bool chunked = s->hmc_chunked && c.L >= 3 && d0.ntc <= CT_MAXC;
-    l.d.chunked = chunked ? 1 : 0;
+    l.d.chunked = chunked ? (d0.Mp <= 512 ? 1 : 2) : 0;     // 1: the M-chunks sum the row partials themselves
     l.d.sp_par = 0;
     launch_se<1>(ctx, l, true);
     launch_hmc(ctx, l, c, s->ch, 0);
@@ -1141,7 +1141,7 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
     if (!mean_ms || iters < 1) return fail(SEIR_ERR_INVALID, "bad iters/mean_ms");
     seir_ctx *ctx = s->ctx;
     LaunchCfg l = whole(ctx, s->cfg.B);
-    l.d.chunked = (s->hmc_chunked && s->cfg.L >= 3 && l.d.ntc <= CT_MAXC) ? 1 : 0;   // the kernel as the sweep runs it
+    l.d.chunked = (s->hmc_chunked && s->cfg.L >= 3 && l.d.ntc <= CT_MAXC) ? (l.d.Mp <= 512 ? 1 : 2) : 0;   // as in the sweep
     launch_se<1>(ctx, l, true);
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; ++i) launch_se<1>(ctx, l, true);
