@@ -402,7 +402,9 @@ inline bool xcd_affinity_applies(int per, int nb) {
     return (nb == 1 || nb == 2 || nb == 4 || nb == 8) && ((long long)per * nb) % 8 == 0;
 }
 
-template <bool GRAD, int SRC>
+// TSM (sampler, GRAD, SRC 1): tile scalars for the chunked leapfrog -- 0 none, 1 column scalars,
+// 2 column and row scalars (Work::TS); compile-time so that the plain kernel carries none of it.
+template <bool GRAD, int SRC, int TSM = 0>
 __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     __shared__ double colbuf[4][WAVE];
     __shared__ double llbuf[4][WAVE], psibuf[4][WAVE];
@@ -442,8 +444,8 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
         }
     }
     // tile scalars for the chunked leapfrog: operands fetched with the other loads
-    const bool ts_on = GRAD && SRC == 1 && d.chunked != 0;
-    const bool ts_rows = GRAD && SRC == 1 && d.chunked == 2;
+    constexpr bool ts_on = GRAD && SRC == 1 && TSM != 0;
+    constexpr bool ts_rows = GRAD && SRC == 1 && TSM == 2;
     double ts_vt = 0.0, ts_l[SE_RW], ts_s[SE_RW];
     // the wave's rows are the same for all its lanes: scalar loads, the values live in SGPRs
     const int m0u = by * SE_TM + __builtin_amdgcn_readfirstlane(wave) * SE_RW;

@@ -298,7 +298,11 @@ static void launch_se(seir_ctx *ctx, const LaunchCfg &l, bool grad) {
     const bool affinity = (l.affinity & 1) && xcd_affinity_applies(d.ntc * d.nmt, l.nb);
     d.aff_nb = affinity ? l.nb : 0;
     const dim3 grid = affinity ? dim3(d.ntc * d.nmt * l.nb) : dim3(d.ntc, d.nmt, l.nb);
-    if (grad)
+    if (grad && SRC == 1 && d.chunked == 1)
+        hipLaunchKernelGGL((k_se<true, SRC, 1>), grid, dim3(256), 0, l.st, d, ctx->c, ctx->w);
+    else if (grad && SRC == 1 && d.chunked == 2)
+        hipLaunchKernelGGL((k_se<true, SRC, 2>), grid, dim3(256), 0, l.st, d, ctx->c, ctx->w);
+    else if (grad)
         hipLaunchKernelGGL((k_se<true, SRC>), grid, dim3(256), 0, l.st, d, ctx->c, ctx->w);
     else
         hipLaunchKernelGGL((k_se<false, SRC>), grid, dim3(256), 0, l.st, d, ctx->c, ctx->w);
@@ -977,9 +981,11 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     hipStream_t st = l.st;
     // [part 0] HMC on u | events: L+1 gradient evaluations
     const bool chunked = s->hmc_chunked && c.L >= 3 && d0.ntc <= CT_MAXC;
-    l.d.chunked = chunked ? (d0.Mp <= 512 ? 1 : 2) : 0;     // 1: the M-chunks sum the row partials themselves
+    const int ts_mode = chunked ? (d0.Mp <= 512 ? 1 : 2) : 0;   // 1: the M-chunks sum the row partials themselves
     l.d.sp_par = 0;
+    l.d.chunked = 0;                       // k_se writes tile scalars only ahead of a chunked step
     launch_se<1>(ctx, l, true);
+    l.d.chunked = ts_mode;                 // stage 0 hands the trajectory over to the chunk kernel
     launch_hmc(ctx, l, c, s->ch, 0);
     if (!chunked) {
         for (int i = 1; i < c.L; ++i) {
@@ -1007,9 +1013,11 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             par ^= 1;
         }
         l.d.sp_par = par;
+        l.d.chunked = 0;
         launch_se<1>(ctx, l, true);
         launch_hmc(ctx, l, c, s->ch, 1, /*gather_qs=*/1);
     }
+    l.d.chunked = 0;
     launch_se<1>(ctx, l, true);
     launch_hmc(ctx, l, c, s->ch, 2);
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
