@@ -1320,11 +1320,13 @@ __device__ __forceinline__ double band_delta(double S, double I, double K0, doub
 // binomial-coefficient terms, so the whole workgroup spreads over that row's days.
 // apply_f != 0 (paired form): the block first writes the F band of the previously accepted E->I update
 // (Chains::fpend) for its own rows -- the only rows whose F it reads below.
-__global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf,
+constexpr int DELTA_THREADS = 256;   // k_move_delta: 4 waves, 2 rows each (8 waves and 4-row blocks measured slower)
+__global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf,
                                                     int apply_f) {
     __shared__ Move mv;
     __shared__ Move fp;
-    __shared__ double sh_th[4], sh_cn[4];
+    constexpr int NW = DELTA_THREADS / WAVE;
+    __shared__ double sh_th[NW], sh_cn[NW];
     __shared__ double2 ltab[LDSTAB_N];
     int bx = blockIdx.x, by = blockIdx.y;
     if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
@@ -1348,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
     log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes mv
     if (apply_f && fp.valid == 1) {
         const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
-        apply_f_band<4>(d, c, w, b, fp, bx * rows_per_blk, min(d.M, (bx + 1) * rows_per_blk));
+        apply_f_band<NW>(d, c, w, b, fp, bx * rows_per_blk, min(d.M, (bx + 1) * rows_per_blk));
         __syncthreads();                           // the band written above is read below
     }
 #ifdef SEIR_STAMPS
@@ -1363,7 +1365,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
         const int r_lo = bx * rows_per_blk, r_hi = min(d.M, r_lo + rows_per_blk);
         const double *ea = w.ea + (size_t)b * d.Tp;
         if (mv.any_dI) {
-            for (int j = r_lo + wave; j < r_hi; j += 4) {
+            for (int j = r_lo + wave; j < r_hi; j += NW) {
                 bool mine = false;
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == j);
@@ -1388,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
             }
         }
         DSTAMP(2);
-        own_rows_delta<256>(d, c, w, b, mv, psi, r_lo, r_hi, ltab, dth, dcn);
+        own_rows_delta<DELTA_THREADS>(d, c, w, b, mv, psi, r_lo, r_hi, ltab, dth, dcn);
     }
     DSTAMP(3);
     dth = wave_sum(dth);
@@ -1397,8 +1399,11 @@ __global__ __launch_bounds__(256) void k_move_delta(Dims d, Consts c, Work w, Sa
     __syncthreads();
     if (threadIdx.x == 0) {
         double *out = ch.Dpart + ((size_t)b * s.nrb_d + bx) * 2;
-        out[0] = sh_th[0] + sh_th[1] + sh_th[2] + sh_th[3];
-        out[1] = sh_cn[0] + sh_cn[1] + sh_cn[2] + sh_cn[3];
+        double a = 0.0, e = 0.0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { a += sh_th[k]; e += sh_cn[k]; }
+        out[0] = a;
+        out[1] = e;
     }
 }
 

@@ -690,7 +690,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     c.chain0 = ds->first_chain_id;
     c.adapt_step = 0; c.adapt_mass = 0; c.n_adapt = 0; c.target_accept = 0.75;
     c.cap = ds->trace_capacity;
-    c.nrb_d = (d.M + 7) / 8;        // row blocks of the move kernels (4 rows per block measured slower: more blocks in k_move_pa2)
+    c.nrb_d = (d.M + 7) / 8;        // row blocks of k_move_delta (4-row blocks measured slower, twice)
     s->record_events = ds->record_events;
     // Launch mode of a sweep's ~76 dependent kernels.  Measured on MI355X / ROCm 7.2 (UK-380, 8 chains):
     // stream launches 0.815 ms per sweep, replay of the captured hipGraph 0.872 ms -- the graph
@@ -1040,7 +1040,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                     hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
                                        have_prev, pbuf);
                     pbuf ^= 1;
-                    hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
+                    hipLaunchKernelGGL(k_move_delta, gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
                 }
             if (have_prev) {
@@ -1061,7 +1061,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                         hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
                                            have_prev, pbuf);
                     pbuf ^= 1;
-                    hipLaunchKernelGGL(k_move_delta, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 0);
+                    hipLaunchKernelGGL(k_move_delta, gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 0);
                     have_prev = 1;
                 }
             if (have_prev) {
