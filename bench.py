@@ -197,6 +197,17 @@ def main():
         for _ in range(50):
             model.log_prob_dev(ut, evt, lp, g)
         evals[name] = B * 50 / (model.timer_stop() * 1e-3)
+    # the same with the event-dependent part prepared once (what the 17 evaluations of an HMC
+    # draw share: state scan, binomial coefficients, E->I term and the mobility contraction)
+    model.prepare_events_dev(evt)
+    for name, g in (("value_events_prepared", None), ("value_and_grad_events_prepared", gr)):
+        for _ in range(3):
+            model.eval_prepared_dev(ut, lp, g)
+        model.sync()
+        model.timer_start()
+        for _ in range(50):
+            model.eval_prepared_dev(ut, lp, g)
+        evals[name] = B * 50 / (model.timer_stop() * 1e-3)
 
     # context for the headline number (N=1 only, not part of `value`): the same sweep with more
     # chains resident on this GPU -- at 8 chains the sweep is bound by its dependent-launch chain,
