@@ -34,6 +34,7 @@ constexpr int MVU = 4;                // cells in flight per thread in the band 
 struct MvShared {
     Move mv;
     int acc;
+    int nsel;                         // rows chosen by the proposal (set by mv_propose)
     int sel[MMAX];
     int ired[MVW * 4];
     double dred[MVW * 2];
@@ -139,8 +140,11 @@ __device__ inline void mv_draw(const SamplerCfg &s, const Chains &ch, int b, Mov
     }
 }
 
+// rows_only: stop after the rows are chosen (sm.nsel, sm.sel[j] = row): what a proposal's rows are
+// depends on the row totals and the uniforms only.
 __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
-                                  MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab) {
+                                  MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab,
+                                  bool rows_only = false) {
     Move &mv = sm.mv;
     const int tid = threadIdx.x, M = d.M, T = d.T, T1 = T + 1;
 #ifdef SEIR_STAMPS
@@ -179,7 +183,9 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
                         --k;
                     }
             }
+        if (tid == 0) sm.nsel = nsel;
         lds_barrier();
+        if (rows_only) return;
         MSTAMP(5);
         // stage the chosen rows: k[t], source and destination compartments at the start of day t in [0,T]
         {
@@ -325,7 +331,9 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
                     }
             }
         }
+        if (tid == 0) sm.nsel = 1;
         lds_barrier();
+        if (rows_only) return;
         MSTAMP(5);
         const int m = sm.sel[0];
         const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
@@ -640,7 +648,6 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
 // which takes a scan from 8 launches to 4.  se.kind < 0: no S->E update; next.kind == -2: closing
 // launch of the sweep (advance the counter).  Random streams, proposal arithmetic and the order
 // of the four updates are those of k_move_pa2 / the oracle.
-// grid (B), MVB threads: one workgroup per chain.
 // ---------------------------------------------------------------------------------------------
 constexpr int PRE_RT = 4;                                      // prefetched rows per thread (M <= 2048)
 
@@ -741,19 +748,53 @@ __device__ __forceinline__ void mv_trace(const SamplerCfg &s, const Chains &ch, 
     }
 }
 
+// The pending E->I-type descriptor is either the speculative one (Chains::mv[buf]) or, when the
+// authoritative workgroup found a row conflict, the one it re-drew (Chains::mvfix, Chains::mvsel = 1).
+// Both are fetched in one round trip; returns the one to use.  Ends with a barrier.
+__device__ __forceinline__ const Move &load_pending(const SamplerCfg &s, const Chains &ch, int b, int buf, Move &A,
+                                                    Move &Bm, int &sel) {
+    if (threadIdx.x == 0) A = ch.mv[(size_t)buf * s.B + b];
+    if (threadIdx.x == 64) Bm = ch.mvfix[(size_t)buf * s.B + b];
+    if (threadIdx.x == 65) sel = ch.mvsel[(size_t)buf * s.B + b];
+    __syncthreads();
+    return sel ? Bm : A;
+}
+
+// sum of k_move_delta's partial log-ratios and the accept decision of the pending proposal
+// (every thread returns the same values)
+__device__ __forceinline__ bool pending_accept(const SamplerCfg &s, const Chains &ch, int b, const Move &pend,
+                                               double *red, double &dth, double &dcn) {
+    dth = 0.0; dcn = 0.0;
+    for (int i = threadIdx.x; i < s.nrb_d; i += MVB) {
+        dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
+        dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
+    }
+    mv_sum2(dth, dcn, red);
+    const double ratio = dth + dcn + pend.logq;
+    return pend.valid && pend.logu < ratio;                  // NaN -> reject
+}
+
+// grid (2 B) x MVB threads: block id = role * B + chain.
+//   role 0, the authoritative workgroup of the chain: (1) finalize the pending E->I-type proposal,
+//     (2) the whole S->E-type update, (3) certify the speculative E->I proposal of role 1 -- its rows
+//     depend on the row totals and the uniforms only, so role 0 recomputes just those; the proposal
+//     is valid unless one of its rows was changed in (1) or (2) (then role 0 draws it again from the
+//     final state into Chains::mvfix and sets Chains::mvsel).
+//   role 1: draws the E->I-type proposal from the state at entry, concurrently with role 0's work.
+//     It has no side effect besides Chains::mv[pbuf^1]; what it reads while role 0 writes can only
+//     be rows of a conflict, which role 0 detects on its own.
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
-                                                   MoveSpec next, int have_prev, int pbuf) {
-    extern __shared__ int dyn_i[];                     // block 0: rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
+                                                   MoveSpec next, int have_prev, int pbuf, int nbk) {
+    extern __shared__ int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm_se, sm_nx;
-    __shared__ Move pend;
+    __shared__ Move pendA, pendB;
     __shared__ double2 ltab[LDSTAB_N];
-    __shared__ int s_acc, s_acc_se;
-    __shared__ double s_dth, s_dcn;
-    // one workgroup per chain: block id = chain keeps the chain <-> XCD affinity of the other kernels
-    const int bx = 0;
-    const int b = d.b0 + blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_sel, s_acc_se, s_conf;
+    const int role = blockIdx.x / nbk;
+    const int b = d.b0 + (int)blockIdx.x - role * nbk, tid = threadIdx.x;
     const int M = d.M, T = d.T;
-    const bool do_se = bx == 0 && se.kind >= 0, do_nx = bx == 0 && next.kind >= 0;
+    const bool do_se = role == 0 && se.kind >= 0, do_nx = next.kind >= 0;
+    if (role == 1 && !do_nx) return;
 #ifdef SEIR_STAMPS
     double *stamp_hs = ch.hs + (size_t)b * NHS;
     const bool stamp_on = do_se && b == 0 && se.slot == (SEIR_STAMP_SLOT & 2) && se.scan == 0;
@@ -769,61 +810,17 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     mv_prefetch_rows(d, w, s, b, next, do_nx && pre_ok, pre_nx);
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
     unsigned tr_slot = 0xffffffffu;
-    if (bx == 0) {
-        if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
-        if (tid == 0) {
-            const double *hs = ch.hs + (size_t)b * NHS;
-            hs_th = hs[HS_LP_THETA]; hs_cn = hs[HS_LP_CONST];
-            tr_slot = ch.sweep[b] - ch.slot0[0];
-        }
-        if (do_se) {
-            psi = w.scal[(size_t)b * NSCAL + SC_PSI];
-            mv_draw(s, ch, b, se, sm_se, T);
-        }
-        if (do_nx) mv_draw(s, ch, b, next, sm_nx, T);
+    if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
+    if (role == 0 && tid == 0) {
+        const double *hs = ch.hs + (size_t)b * NHS;
+        hs_th = hs[HS_LP_THETA]; hs_cn = hs[HS_LP_CONST];
+        tr_slot = ch.sweep[b] - ch.slot0[0];
     }
-    // ---- (1) finalize the pending E->I-type proposal
-    bool pend_acc = false;
-    if (!have_prev && tid == 64) ch.fpend[b].valid = 0;   // first launch of a sweep: nothing pending
-    if (have_prev) {
-        if (tid == 0) pend = ch.mv[(size_t)pbuf * s.B + b];
-        double dth = 0.0, dcn = 0.0;
-        for (int i = tid; i < s.nrb_d; i += MVB) {
-            dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
-            dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
-        }
-        mv_sum2(dth, dcn, sm_nx.dred);
-        if (tid == 0) {
-            const double ratio = dth + dcn + pend.logq;
-            s_acc = (pend.valid && pend.logu < ratio) ? 1 : 0;   // NaN -> reject
-            s_dth = dth; s_dcn = dcn;
-        }
-        __syncthreads();
-        pend_acc = s_acc != 0;
-        const Move &mv = pend;
-        // The F band of an accepted E->I update is NOT written here: k_move_delta (or k_apply_fpend at the
-        // end of the sweep) does it with the whole chip; the S->E update below adds the pending band to
-        // the F values it reads.
-        if (tid == 64) {
-            Move *fp = ch.fpend + b;
-            if (pend_acc && mv.any_dI) { *fp = mv; fp->valid = 1; }
-            else fp->valid = 0;
-        }
-        if (bx == 0) {
-            if (pend_acc) mv_apply_rows(d, w, b, mv);
-            if (tid == 0) {
-                if (pend_acc) {
-                    double *hs = ch.hs + (size_t)b * NHS;
-                    hs_th += s_dth; hs_cn += s_dcn;
-                    hs[HS_LP_THETA] = hs_th; hs[HS_LP_CONST] = hs_cn;
-                }
-                mv_trace(s, ch, b, mv, s_acc, tr_slot, hs_th + hs_cn);
-            }
-            lds_barrier();
-        }
+    if (do_se) {
+        psi = w.scal[(size_t)b * NSCAL + SC_PSI];
+        mv_draw(s, ch, b, se, sm_se, T);
     }
-    if (bx != 0) return;
-    PSTAMP(1);
+    if (do_nx) mv_draw(s, ch, b, next, sm_nx, T);
     MvLds L{};
     int *rtl = dyn_i + M;
     L.rt = rtl;
@@ -832,7 +829,48 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     L.rk = dyn_i + 2 * M;
     L.rsrc = L.rk + MMAX * (T + 1);
     L.rdst = L.rsrc + MMAX * (T + 1);
+    // ---- (1) the pending E->I-type proposal: both roles need the decision, role 0 acts on it
+    bool pend_acc = false;
+    double dth0 = 0.0, dcn0 = 0.0;
+    const Move *pendp = nullptr;
+    if (have_prev) {
+        const Move &pend = load_pending(s, ch, b, pbuf, pendA, pendB, s_sel);
+        pendp = &pend;
+        pend_acc = pending_accept(s, ch, b, pend, sm_nx.dred, dth0, dcn0);
+    }
+    if (role == 1) {
+        // ------------------------------------------------------------ speculative E->I-type proposal
+        const Move *fix = (pend_acc && pendp->tgt == next.tgt) ? pendp : nullptr;
+        mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
+        mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
+        if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
+        return;
+    }
+    if (!have_prev && tid == 64) ch.fpend[b].valid = 0;    // first launch of a sweep: nothing pending
+    if (have_prev) {
+        const Move &mv = *pendp;
+        // The F band of an accepted E->I update is NOT written here: k_move_delta (or k_apply_fpend at the
+        // end of the sweep) does it with the whole chip; the S->E update below adds the pending band to
+        // the F values it reads.
+        if (tid == 64) {
+            Move *fp = ch.fpend + b;
+            if (pend_acc && mv.any_dI) { *fp = mv; fp->valid = 1; }
+            else fp->valid = 0;
+        }
+        if (pend_acc) mv_apply_rows(d, w, b, mv);
+        if (tid == 0) {
+            if (pend_acc) {
+                double *hs = ch.hs + (size_t)b * NHS;
+                hs_th += dth0; hs_cn += dcn0;
+                hs[HS_LP_THETA] = hs_th; hs[HS_LP_CONST] = hs_cn;
+            }
+            mv_trace(s, ch, b, mv, pend_acc ? 1 : 0, tr_slot, hs_th + hs_cn);
+        }
+        lds_barrier();
+    }
+    PSTAMP(1);
     // ---- (2) the whole S->E-type update
+    bool se_acc = false;
     if (do_se) {
         // the pending update was of the other plane (tgt 1): nothing to correct in plane 0's totals
         mv_rows_to_lds(d, w, s, b, se, pre_ok, pre_se, nullptr, L, rtl);
@@ -841,7 +879,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         PSTAMP(3);
         const Move &mv = sm_se.mv;
         double dth = 0.0, dcn = 0.0;
-        const Move *fpp = (have_prev && pend_acc && pend.any_dI) ? &pend : nullptr;
+        const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
         if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, M, ltab, dth, dcn, fpp);
         PSTAMP(4);
         mv_sum2(dth, dcn, sm_se.dred);
@@ -850,32 +888,47 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
             s_acc_se = (mv.valid && mv.logu < ratio) ? 1 : 0;    // NaN -> reject
         }
         lds_barrier();
-        const bool acc = s_acc_se != 0;
-        if (acc) mv_apply_rows(d, w, b, mv);
+        se_acc = s_acc_se != 0;
+        if (se_acc) mv_apply_rows(d, w, b, mv);
         if (tid == 0) {
-            if (acc) {
+            if (se_acc) {
                 double *hs = ch.hs + (size_t)b * NHS;
                 hs_th += dth; hs_cn += dcn;
                 hs[HS_LP_THETA] = hs_th; hs[HS_LP_CONST] = hs_cn;
             }
             mv_trace(s, ch, b, mv, s_acc_se, tr_slot, hs_th + hs_cn);
         }
-        __syncthreads();             // rows staged for (3) must see the state written above
+        __syncthreads();             // a re-drawn proposal in (3) must see the state written above
         PSTAMP(5);
     }
-    // ---- (3) proposal for the following k_move_delta; closing launch: advance the sweep counter
+    // ---- (3) certify role 1's proposal; closing launch: advance the sweep counter
     if (next.kind == -2 && tid == 0) ch.sweep[b] += 1;
     if (do_nx) {
         // plane 1 totals were prefetched before (1): correct them if the pending (plane 1) update was accepted
-        const Move *fix = (have_prev && pend_acc && pend.tgt == next.tgt) ? &pend : nullptr;
+        const Move *fix = (pend_acc && pendp->tgt == next.tgt) ? pendp : nullptr;
         mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
         PSTAMP(6);
-        mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
-        if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
+        mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab, /*rows_only=*/true);
+        if (tid == 0) {
+            int conf = 0;
+            for (int j = 0; j < sm_nx.nsel; ++j) {
+                const int row = sm_nx.sel[j];
+                if (se_acc)
+                    for (int i = 0; i < sm_se.mv.n; ++i) conf |= sm_se.mv.m[i] == row;
+                if (pend_acc)
+                    for (int i = 0; i < pendp->n; ++i) conf |= pendp->m[i] == row;
+            }
+            s_conf = conf;
+            ch.mvsel[(size_t)(pbuf ^ 1) * s.B + b] = conf;   // double-buffered like Chains::mv: a late role 1 still reads the old one
+        }
+        lds_barrier();
+        if (s_conf) {                                        // rare: draw it again from the final state
+            mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
+            if (tid == 0) ch.mvfix[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
+        }
         PSTAMP(7);
     }
 }
-
 
 inline size_t k_move_pa2_lds_bytes(const Dims &d) {
     return sizeof(int) * ((size_t)2 * d.M + 3 * MMAX * (d.T + 1));

@@ -69,6 +69,8 @@ struct Chains {
     double *hs;                                          // [B][NHS]
     Move *mv;                                            // [2][B] double-buffered proposal descriptors
     Move *fpend;                                         // [B] accepted E->I-type update whose F band is still to be applied (valid = 1)
+    Move *mvfix;                                         // [2][B] E->I-type proposal re-drawn after a row conflict (k_move_pair)
+    int *mvsel;                                          // [2][B] 1: the pending descriptor is mvfix, 0: mv[buf]
     double *Dpart;                                       // [B][nrb_d][2]
     unsigned *sweep;                                     // [B] sweeps done (device resident: graph replays advance it)
     unsigned *slot0;                                     // [1] sweep index of trace slot 0
@@ -1323,7 +1325,8 @@ __device__ __forceinline__ double band_delta(double S, double I, double K0, doub
 constexpr int DELTA_THREADS = 256;   // k_move_delta: 4 waves, 2 rows each (8 waves and 4-row blocks measured slower)
 __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf,
                                                     int apply_f) {
-    __shared__ Move mv;
+    __shared__ Move mvA, mvB;
+    __shared__ int mv_sel;
     __shared__ Move fp;
     constexpr int NW = DELTA_THREADS / WAVE;
     __shared__ double sh_th[NW], sh_cn[NW];
@@ -1345,9 +1348,12 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
 #define DSTAMP(i) do {} while (0)
 #endif
     DSTAMP(0);
-    if (threadIdx.x == 0) mv = ch.mv[(size_t)buf * s.B + b];
-    if (apply_f && threadIdx.x == 64) fp = ch.fpend[b];
-    log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes mv
+    if (threadIdx.x == 0) mvA = ch.mv[(size_t)buf * s.B + b];
+    if (threadIdx.x == 64) mvB = ch.mvfix[(size_t)buf * s.B + b];
+    if (threadIdx.x == 65) mv_sel = ch.mvsel[(size_t)buf * s.B + b];
+    if (apply_f && threadIdx.x == 128) fp = ch.fpend[b];
+    log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes the descriptors
+    const Move &mv = mv_sel ? mvB : mvA;           // see load_pending() in moves_kernel.h
     if (apply_f && fp.valid == 1) {
         const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
         apply_f_band<NW>(d, c, w, b, fp, bx * rows_per_blk, min(d.M, (bx + 1) * rows_per_blk));

@@ -737,6 +737,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.hs, (size_t)B * NHS);
     S_ALLOC(ch.mv, (size_t)2 * B);
     S_ALLOC(ch.fpend, (size_t)B);
+    S_ALLOC(ch.mvfix, (size_t)2 * B);
+    S_ALLOC(ch.mvsel, (size_t)2 * B);
     S_ALLOC(ch.Dpart, (size_t)B * c.nrb_d * 2);
     S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
     S_ALLOC(ch.tr_theta, (size_t)c.cap * B * d.P);
@@ -1037,8 +1039,8 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             for (int scan = 0; scan < c.n_scans; ++scan)
                 for (int half = 0; half < 2; ++half) {
                     const MoveSpec se{half, 0, 2 * half, scan}, nx{half, 1, 2 * half + 1, scan};
-                    hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
-                                       have_prev, pbuf);
+                    hipLaunchKernelGGL(k_move_pair, dim3(2 * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
+                                       have_prev, pbuf, nb);
                     pbuf ^= 1;
                     hipLaunchKernelGGL(k_move_delta, gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
@@ -1046,7 +1048,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             if (have_prev) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
                 hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, 1,
-                                   pbuf);
+                                   pbuf, nb);
                 hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
                 advanced = 1;
             }
