@@ -762,16 +762,34 @@ __device__ __forceinline__ const Move &load_pending(const SamplerCfg &s, const C
 
 // sum of k_move_delta's partial log-ratios and the accept decision of the pending proposal
 // (every thread returns the same values)
-__device__ __forceinline__ bool pending_accept(const SamplerCfg &s, const Chains &ch, int b, const Move &pend,
-                                               double *red, double &dth, double &dcn) {
+__device__ __forceinline__ bool pending_accept(const SamplerCfg &s, const Chains &ch, int b, int buf, int sel,
+                                               const Move &pend, double *red, double &dth, double &dcn) {
     dth = 0.0; dcn = 0.0;
     for (int i = threadIdx.x; i < s.nrb_d; i += MVB) {
         dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
         dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
     }
     mv_sum2(dth, dcn, red);
+    const double *od = ch.Down + (((size_t)buf * 2 + (sel ? 1 : 0)) * s.B + b) * 2;   // the updated rows' part
+    dth += od[0];
+    dcn += od[1];
     const double ratio = dth + dcn + pend.logq;
     return pend.valid && pend.logu < ratio;                  // NaN -> reject
+}
+
+// log-ratio of a drawn E->I-type proposal over the rows it updates -> Chains::Down[parity][which][chain]
+__device__ __forceinline__ void mv_own_rows_to_down(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
+                                                    const Chains &ch, int b, const Move &mv, double psi,
+                                                    const double2 *ltab, const Move *fp, double *red, int parity,
+                                                    int which) {
+    double dth = 0.0, dcn = 0.0;
+    if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, d.M, ltab, dth, dcn, fp);
+    mv_sum2(dth, dcn, red);
+    if (threadIdx.x == 0) {
+        double *od = ch.Down + (((size_t)parity * 2 + which) * s.B + b) * 2;
+        od[0] = dth;
+        od[1] = dcn;
+    }
 }
 
 // grid (2 B) x MVB threads: block id = role * B + chain.
@@ -816,10 +834,8 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         hs_th = hs[HS_LP_THETA]; hs_cn = hs[HS_LP_CONST];
         tr_slot = ch.sweep[b] - ch.slot0[0];
     }
-    if (do_se) {
-        psi = w.scal[(size_t)b * NSCAL + SC_PSI];
-        mv_draw(s, ch, b, se, sm_se, T);
-    }
+    if (do_se || do_nx) psi = w.scal[(size_t)b * NSCAL + SC_PSI];
+    if (do_se) mv_draw(s, ch, b, se, sm_se, T);
     if (do_nx) mv_draw(s, ch, b, next, sm_nx, T);
     MvLds L{};
     int *rtl = dyn_i + M;
@@ -836,7 +852,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     if (have_prev) {
         const Move &pend = load_pending(s, ch, b, pbuf, pendA, pendB, s_sel);
         pendp = &pend;
-        pend_acc = pending_accept(s, ch, b, pend, sm_nx.dred, dth0, dcn0);
+        pend_acc = pending_accept(s, ch, b, pbuf, s_sel, pend, sm_nx.dred, dth0, dcn0);
     }
     if (role == 1) {
         // ------------------------------------------------------------ speculative E->I-type proposal
@@ -844,6 +860,10 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
         mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
         if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
+        // ... and its log-ratio over the rows it updates (k_move_delta then does the band only); the F band
+        // of an accepted pending update is not in F yet and is added on the fly
+        const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
+        mv_own_rows_to_down(d, c, w, s, ch, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred, pbuf ^ 1, 0);
         return;
     }
     if (!have_prev && tid == 64) ch.fpend[b].valid = 0;    // first launch of a sweep: nothing pending
@@ -925,6 +945,8 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         if (s_conf) {                                        // rare: draw it again from the final state
             mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
             if (tid == 0) ch.mvfix[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
+            const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
+            mv_own_rows_to_down(d, c, w, s, ch, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred, pbuf ^ 1, 1);
         }
         PSTAMP(7);
     }

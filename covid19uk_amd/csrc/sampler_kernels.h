@@ -72,6 +72,8 @@ struct Chains {
     Move *mvfix;                                         // [2][B] E->I-type proposal re-drawn after a row conflict (k_move_pair)
     int *mvsel;                                          // [2][B] 1: the pending descriptor is mvfix, 0: mv[buf]
     double *Dpart;                                       // [B][nrb_d][2]
+    double *Down;                                        // [2][2][B][2] paired form: own-rows log-ratio of the speculative /
+                                                         // re-drawn E->I proposal (parity, which, chain, {theta, const})
     unsigned *sweep;                                     // [B] sweeps done (device resident: graph replays advance it)
     unsigned *slot0;                                     // [1] sweep index of trace slot 0
     // traces
@@ -1396,7 +1398,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
             }
         }
         DSTAMP(2);
-        own_rows_delta<DELTA_THREADS>(d, c, w, b, mv, psi, r_lo, r_hi, ltab, dth, dcn);
+        // paired form (apply_f): k_move_pair's workgroups have the updated rows' part already (Chains::Down)
+        if (!apply_f) own_rows_delta<DELTA_THREADS>(d, c, w, b, mv, psi, r_lo, r_hi, ltab, dth, dcn);
     }
     DSTAMP(3);
     dth = wave_sum(dth);

@@ -740,6 +740,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.mvfix, (size_t)2 * B);
     S_ALLOC(ch.mvsel, (size_t)2 * B);
     S_ALLOC(ch.Dpart, (size_t)B * c.nrb_d * 2);
+    S_ALLOC(ch.Down, (size_t)2 * 2 * B * 2);
     S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
     S_ALLOC(ch.tr_theta, (size_t)c.cap * B * d.P);
     S_ALLOC(ch.tr_events, s->record_events ? (size_t)c.cap * B * d.M * d.T * 3 : 1);
