@@ -799,15 +799,18 @@ __device__ __forceinline__ void mv_own_rows_to_down(const Dims &d, const Consts 
 //     is valid unless one of its rows was changed in (1) or (2) (then role 0 draws it again from the
 //     final state into Chains::mvfix and sets Chains::mvsel).
 //   role 1: draws the E->I-type proposal from the state at entry, concurrently with role 0's work.
-//     It has no side effect besides Chains::mv[pbuf^1]; what it reads while role 0 writes can only
-//     be rows of a conflict, which role 0 detects on its own.
+//     It has no side effect besides Chains::mv[pbuf^1] and Chains::Down.  What it reads is of two kinds:
+//     rows of the planes -- if role 0 writes one of them in (1) or (2) it is a row of a conflict, which
+//     role 0 detects on its own; and the plane's row/range totals, fetched at entry -- role 0 does not
+//     write anything before role 1 has them (one-word handshake, Chains::hand; if role 1 is not
+//     there in time role 0 goes on and re-draws the proposal itself).
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
-                                                   MoveSpec next, int have_prev, int pbuf, int nbk) {
+                                                   MoveSpec next, int have_prev, int pbuf, int nbk, int lidx) {
     extern __shared__ int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
     __shared__ double2 ltab[LDSTAB_N];
-    __shared__ int s_sel, s_acc_se, s_conf;
+    __shared__ int s_sel, s_acc_se, s_conf, s_late;
     const int role = blockIdx.x / nbk;
     const int b = d.b0 + (int)blockIdx.x - role * nbk, tid = threadIdx.x;
     const int M = d.M, T = d.T;
@@ -826,6 +829,13 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     int pre_se[PRE_RT], pre_nx[PRE_RT];
     mv_prefetch_rows(d, w, s, b, se, do_se && pre_ok, pre_se);
     mv_prefetch_rows(d, w, s, b, next, do_nx && pre_ok, pre_nx);
+    const unsigned token = ch.sweep[b] * 64u + (unsigned)lidx + 1u;       // unique per (sweep, launch): lidx < 63
+    if (role == 1) {
+        // the totals are in registers: tell role 0 it may start writing
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ch.hand + b, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
     unsigned tr_slot = 0xffffffffu;
     if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
@@ -867,8 +877,25 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         return;
     }
     if (!have_prev && tid == 64) ch.fpend[b].valid = 0;    // first launch of a sweep: nothing pending
+    // before the first store role 1 could mistake for the state at entry: has it fetched its totals?
+    // (bounded wait; normally role 1 is long past that point when the accept test above is done)
+    bool late = false;
+    auto wait_role1 = [&]() {
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(ch.hand + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token && spins < 4000) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+            }
+            s_late = spins >= 4000 ? 1 : 0;
+        }
+        lds_barrier();
+        late = s_late != 0;
+    };
+    bool waited = !do_nx;                                  // no role 1 in this launch: nothing to wait for
     if (have_prev) {
         const Move &mv = *pendp;
+        if (pend_acc && !waited) { wait_role1(); waited = true; }
         // The F band of an accepted E->I update is NOT written here: k_move_delta (or k_apply_fpend at the
         // end of the sweep) does it with the whole chip; the S->E update below adds the pending band to
         // the F values it reads.
@@ -909,6 +936,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         }
         lds_barrier();
         se_acc = s_acc_se != 0;
+        if (se_acc && !waited) { wait_role1(); waited = true; }
         if (se_acc) mv_apply_rows(d, w, b, mv);
         if (tid == 0) {
             if (se_acc) {
@@ -924,20 +952,25 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     // ---- (3) certify role 1's proposal; closing launch: advance the sweep counter
     if (next.kind == -2 && tid == 0) ch.sweep[b] += 1;
     if (do_nx) {
-        // plane 1 totals were prefetched before (1): correct them if the pending (plane 1) update was accepted
-        const Move *fix = (pend_acc && pendp->tgt == next.tgt) ? pendp : nullptr;
-        mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
-        PSTAMP(6);
-        mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab, /*rows_only=*/true);
+        // nothing was accepted in (1) and (2): the state role 1 read is the final one, no row can conflict
+        const bool changed = se_acc || pend_acc;             // uniform
+        if (changed) {
+            // plane 1 totals were prefetched before (1): correct them if the pending (plane 1) update was accepted
+            const Move *fix = (pend_acc && pendp->tgt == next.tgt) ? pendp : nullptr;
+            mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
+            PSTAMP(6);
+            mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab, /*rows_only=*/true);
+        }
         if (tid == 0) {
-            int conf = 0;
-            for (int j = 0; j < sm_nx.nsel; ++j) {
-                const int row = sm_nx.sel[j];
-                if (se_acc)
-                    for (int i = 0; i < sm_se.mv.n; ++i) conf |= sm_se.mv.m[i] == row;
-                if (pend_acc)
-                    for (int i = 0; i < pendp->n; ++i) conf |= pendp->m[i] == row;
-            }
+            int conf = late ? 1 : 0;                         // role 1 was not there in time: do not trust it
+            if (changed)
+                for (int j = 0; j < sm_nx.nsel; ++j) {
+                    const int row = sm_nx.sel[j];
+                    if (se_acc)
+                        for (int i = 0; i < sm_se.mv.n; ++i) conf |= sm_se.mv.m[i] == row;
+                    if (pend_acc)
+                        for (int i = 0; i < pendp->n; ++i) conf |= pendp->m[i] == row;
+                }
             s_conf = conf;
             ch.mvsel[(size_t)(pbuf ^ 1) * s.B + b] = conf;   // double-buffered like Chains::mv: a late role 1 still reads the old one
         }

@@ -70,6 +70,7 @@ struct Chains {
     Move *mv;                                            // [2][B] double-buffered proposal descriptors
     Move *fpend;                                         // [B] accepted E->I-type update whose F band is still to be applied (valid = 1)
     Move *mvfix;                                         // [2][B] E->I-type proposal re-drawn after a row conflict (k_move_pair)
+    unsigned *hand;                                      // [B] k_move_pair: token of the launch whose role 1 has its totals
     int *mvsel;                                          // [2][B] 1: the pending descriptor is mvfix, 0: mv[buf]
     double *Dpart;                                       // [B][nrb_d][2]
     double *Down;                                        // [2][2][B][2] paired form: own-rows log-ratio of the speculative /

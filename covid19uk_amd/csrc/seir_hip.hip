@@ -739,6 +739,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.fpend, (size_t)B);
     S_ALLOC(ch.mvfix, (size_t)2 * B);
     S_ALLOC(ch.mvsel, (size_t)2 * B);
+    S_ALLOC(ch.hand, (size_t)B);
     S_ALLOC(ch.Dpart, (size_t)B * c.nrb_d * 2);
     S_ALLOC(ch.Down, (size_t)2 * 2 * B * 2);
     S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
@@ -1034,6 +1035,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
         int have_prev = 0, pbuf = 0;
+        if (s->moves_mode == 0 && c.n_scans > 30) s->moves_mode = 1;   // k_move_pair's launch tokens cover 62 launches per sweep
         if (s->moves_mode == 0) {
             // paired form: [finalize pending E->I-type | whole S->E-type update | propose E->I-type], then
             // the log-ratio of the E->I-type proposal over its band: 4 launches per scan
@@ -1041,7 +1043,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                 for (int half = 0; half < 2; ++half) {
                     const MoveSpec se{half, 0, 2 * half, scan}, nx{half, 1, 2 * half + 1, scan};
                     hipLaunchKernelGGL(k_move_pair, dim3(2 * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
-                                       have_prev, pbuf, nb);
+                                       have_prev, pbuf, nb, 2 * scan + half);
                     pbuf ^= 1;
                     hipLaunchKernelGGL(k_move_delta, gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
@@ -1049,7 +1051,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             if (have_prev) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
                 hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, 1,
-                                   pbuf, nb);
+                                   pbuf, nb, 62);
                 hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
                 advanced = 1;
             }
