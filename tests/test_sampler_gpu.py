@@ -197,6 +197,33 @@ def test_running_log_prob_matches_full_reevaluation_syn2048(api):
         assert np.array_equal(tr.events[-1, b], ev1[b].astype(np.int32))
 
 
+def test_paired_and_split_launch_forms_agree_at_uk380(api, monkeypatch):
+    """The paired form (k_move_pair: S->E updates inside the proposing workgroup, speculative E->I
+    proposal certified by row comparison, deferred F band) against one-kernel-per-update on the
+    BASELINE size, where row conflicts are rare events: the same proposals, decisions and events."""
+    SeirModel, ChainSampler = api
+    case = H.build_case("uk380", 12)
+    B, n = 4, 40
+    u, ev = _start(case, B, 12, scale=0.002)
+    out = {}
+    for mode in ("paired", "split"):
+        monkeypatch.setenv("SEIR_MOVES", mode)
+        with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+            with ChainSampler(model, CFG_REF, B, seed=21, trace_capacity=n) as s:
+                s.set_state(u, ev)
+                s.set_kernel(step_size=1.5e-5)
+                out[mode] = s.sample(n)
+    a, b_ = out["paired"], out["split"]
+    assert np.array_equal(a.events, b_.events)
+    for key in a.moves:
+        assert np.array_equal(a.moves[key]["proposed_delta"], b_.moves[key]["proposed_delta"]), key
+        assert np.array_equal(a.moves[key]["is_accepted"], b_.moves[key]["is_accepted"]), key
+        assert np.allclose(a.moves[key]["target_log_prob"], b_.moves[key]["target_log_prob"], rtol=1e-11, atol=0)
+    assert np.array_equal(a.hmc["is_accepted"], b_.hmc["is_accepted"])
+    assert np.allclose(a.theta, b_.theta, rtol=1e-9, atol=1e-12)
+    assert sum(int(a.moves[k]["is_accepted"].sum()) for k in a.moves) > 50
+
+
 def test_chains_are_independent_of_batch_composition(api):
     """Chain c's draws depend only on (seed, global chain id): running chains {0,1,2,3}
     together or chain 2 alone (first_chain_id=2) gives bit-identical traces -- the
