@@ -805,7 +805,7 @@ __device__ __forceinline__ void mv_own_rows_to_down(const Dims &d, const Consts 
 //     write anything before role 1 has them (one-word handshake, Chains::hand; if role 1 is not
 //     there in time role 0 goes on and re-draws the proposal itself).
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
-                                                   MoveSpec next, int have_prev, int pbuf, int nbk, int lidx) {
+                                                   MoveSpec next, int have_prev, int pbuf, int nbk, int lidx, int dbg) {
     extern __shared__ int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
@@ -834,7 +834,10 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         // the totals are in registers: tell role 0 it may start writing
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(ch.hand + b, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // test hooks (SEIR_DEBUG_PAIR): 1 = post the token late, 2 = never post it
+        if (dbg & 1)
+            for (int i = 0; i < 400; ++i) __builtin_amdgcn_s_sleep(127);
+        if (tid == 0 && !(dbg & 2)) __hip_atomic_store(ch.hand + b, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
     unsigned tr_slot = 0xffffffffu;

@@ -625,6 +625,7 @@ struct seir_sampler {
     bool use_graph = true;
     bool legacy_moves = false;    // SEIR_MOVES=legacy: first implementation of the proposal kernel (k_move_pa)
     bool hmc_chunked = true;      // SEIR_HMC=single: every leapfrog step by the single-workgroup kernel
+    int pair_debug = 0;           // SEIR_DEBUG_PAIR: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
     int moves_mode = 0;           // 0 = paired launches (k_move_pair); 1 = one proposal kernel per update (split / legacy)
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
@@ -701,6 +702,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         s->use_graph = e && atoi(e) != 0 && getenv("SEIR_NO_GRAPH") == nullptr;
     }
     {
+        const char *dbgp = getenv("SEIR_DEBUG_PAIR");
+        s->pair_debug = dbgp ? atoi(dbgp) : 0;
         const char *h = getenv("SEIR_HMC");
         s->hmc_chunked = !(h && strcmp(h, "single") == 0);
         // SEIR_MOVES: (default) paired launches | "split": k_move_pa2 per update | "legacy": k_move_pa per update
@@ -1043,7 +1046,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                 for (int half = 0; half < 2; ++half) {
                     const MoveSpec se{half, 0, 2 * half, scan}, nx{half, 1, 2 * half + 1, scan};
                     hipLaunchKernelGGL(k_move_pair, dim3(2 * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
-                                       have_prev, pbuf, nb, 2 * scan + half);
+                                       have_prev, pbuf, nb, 2 * scan + half, s->pair_debug);
                     pbuf ^= 1;
                     hipLaunchKernelGGL(k_move_delta, gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
@@ -1051,7 +1054,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             if (have_prev) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
                 hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, 1,
-                                   pbuf, nb, 62);
+                                   pbuf, nb, 62, 0);
                 hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
                 advanced = 1;
             }

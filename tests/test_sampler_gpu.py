@@ -197,6 +197,28 @@ def test_running_log_prob_matches_full_reevaluation_syn2048(api):
         assert np.array_equal(tr.events[-1, b], ev1[b].astype(np.int32))
 
 
+@pytest.mark.parametrize("hook", ["1", "2"])
+def test_pair_kernel_handshake_paths(api, monkeypatch, hook):
+    """k_move_pair's role 0 waits for role 1's token before its first store (hook 1: the token comes
+    late) and re-draws the E->I proposal itself when role 1 never shows up (hook 2): same traces."""
+    monkeypatch.setenv("SEIR_DEBUG_PAIR", hook)
+    SeirModel, ChainSampler = api
+    case = H.build_case("micro_5x24", 1, alpha_t_sd=0.005)
+    B, n = 2, 6
+    u, ev = _start(case, B, 1)
+    oracles = []
+    for b in range(B):
+        ch = mo.OracleChain(case["k"], CFG_SMALL, u[b], ev[b], seed=77, chain_id=5 + b)
+        ch.eps = 0.002
+        oracles.append([ch.sweep_once() for _ in range(n)])
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, CFG_SMALL, B, seed=77, first_chain_id=5, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.002)
+            tr = s.sample(n)
+    _compare(tr, oracles, n, B, CFG_SMALL)
+
+
 def test_paired_and_split_launch_forms_agree_at_uk380(api, monkeypatch):
     """The paired form (k_move_pair: S->E updates inside the proposing workgroup, speculative E->I
     proposal certified by row comparison, deferred F band) against one-kernel-per-update on the
