@@ -1240,14 +1240,25 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
                     if (i < fp->n && t > fp->lo[i] && t <= fp->hi[i]) F += cfp[i];
             }
             const double ee = ea[t] * eb, psiW = psi * c.W[t];
-            const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
-            const double L_ir = log1mexp(r_ir, ltab);
-            double th0, cn0, th1, cn1;
-            cell_terms(d, S, E, I, kse, kei, kir, F, ee, psiW, r_ir, L_ir, L_ei, r_ei, ltab, th0, cn0);
-            cell_terms(d, S + dS, E + dE, I + dI, kse + dk0, kei + dk1, kir, F + dF, ee, psiW, r_ir, L_ir, L_ei,
-                       r_ei, ltab, th1, cn1);
-            dth += th1 - th0;
-            dcn += cn1 - cn0;
+            // only the terms the update changes (cell_terms(new) - cell_terms(old) with the rest cancelled):
+            // 4 instead of 6 binomial coefficients, no I->R log
+            const double rr0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
+            if (mv.tgt == 0) {
+                // S, k_se and E move; the S->E rate (I, F) does not
+                const double L0 = log1mexp(rr0, ltab);
+                const double k1 = kse + dk0;
+                dth += ((k1 != 0.0 ? k1 * L0 : 0.0) - (kse != 0.0 ? kse * L0 : 0.0)) - (double)(dS - dk0) * rr0;
+                dcn += (lbinom(S + dS, k1, ltab) - lbinom(S, kse, ltab)) + (lbinom(E + dE, kei, ltab) - lbinom(E, kei, ltab)) -
+                       (double)dE * r_ei;
+            } else {
+                // E, k_ei and I move, and F with them; S and k_se do not
+                const double rr1 = (ee * ((I + dI) + psiW * (F + dF)) + d.rate_floor) * d.dt;
+                const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
+                dth += (kse != 0.0 ? kse * (log1mexp(rr1, ltab) - log1mexp(rr0, ltab)) : 0.0) - (S - kse) * (rr1 - rr0) -
+                       (double)dI * r_ir;
+                dcn += (lbinom(E + dE, kei + dk1, ltab) - lbinom(E, kei, ltab)) + (lbinom(I + dI, kir, ltab) - lbinom(I, kir, ltab)) +
+                       (double)dk1 * L_ei - (double)(dE - dk1) * r_ei;
+            }
         }
     }
 }
