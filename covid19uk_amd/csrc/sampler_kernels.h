@@ -212,6 +212,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     __shared__ double scn[HWV];
     __shared__ double bc[12];                          // broadcast scalars
     __shared__ double bc2[2];
+    __shared__ double zz[6];                           // stage 0: standard normals of the six global parameters
     __shared__ int s_accept;
     __shared__ double2 ltab[LDSTAB_N];
     const int b = d.b0 + blockIdx.x, tid = threadIdx.x;
@@ -307,6 +308,17 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         for (int i = 0; i < 6; ++i) { q6[i] = q[i]; p6[i] = STAGE == 0 ? 0.0 : p[i]; v6[i] = var[i]; }
     }
     STAMP_DRAIN(12);
+    // stage 0: the momentum draws depend on nothing loaded above -- done here they overlap the load latency
+    // (the six global parameters by six lanes of the last wave instead of one lane six times)
+    double zt[HT], zm[HM];
+    if (STAGE == 0) {
+        const RngKey key = rng_key(s, ch, b);
+#pragma unroll
+        for (int k = 0; k < HT; ++k) { const int t = tid + k * HB; zt[k] = (t >= 1 && t < T) ? momentum_normal(key, oT + t) : 0.0; }
+#pragma unroll
+        for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; zm[k] = m < M ? momentum_normal(key, oM + m) : 0.0; }
+        if (tid >= HB - 8 && tid < HB - 2) zz[tid - (HB - 8)] = momentum_normal(key, tid - (HB - 8));
+    }
     if (gather_qs) {                                   // uniform branch
 #pragma unroll
         for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; if (m < M) lds_sp[m] = qm[k]; }
@@ -385,13 +397,11 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     // ---------------- phase 2: leapfrog on the owned entries -------------------
     double kin = 0.0;                                   // kinetic energy contribution (STAGE 0: start, 2: end)
     if (STAGE == 0) {
-        const RngKey key = rng_key(s, ch, b);
-        auto draw = [&](int i) { return momentum_normal(key, i); };
 #pragma unroll
         for (int k = 0; k < HT; ++k) {
             const int t = tid + k * HB;
             if (t >= 1 && t < T) {
-                double pi = draw(oT + t) / sqrt(va[k]);
+                double pi = zt[k] / sqrt(va[k]);
                 kin += 0.5 * va[k] * pi * pi;
                 q0[oT + t] = qa[k];
                 pi += 0.5 * eps * ga[k];
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         for (int k = 0; k < HM; ++k) {
             const int m = tid + k * HB;
             if (m < M) {
-                double pi = draw(oM + m) / sqrt(vm[k]);
+                double pi = zm[k] / sqrt(vm[k]);
                 kin += 0.5 * vm[k] * pi * pi;
                 q0[oM + m] = qm[k];
                 pi += 0.5 * eps * gm[k];
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         if (tid == 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                double pi = draw(i) / sqrt(v6[i]);
+                double pi = zz[i] / sqrt(v6[i]);
                 kin += 0.5 * v6[i] * pi * pi;
                 q0[i] = q6[i];
                 pi += 0.5 * eps * g6[i];
