@@ -1346,7 +1346,10 @@ __device__ __forceinline__ double band_delta(double S, double I, double K0, doub
 // binomial-coefficient terms, so the whole workgroup spreads over that row's days.
 // apply_f != 0 (paired form): the block first writes the F band of the previously accepted E->I update
 // (Chains::fpend) for its own rows -- the only rows whose F it reads below.
+// OWN: also the updated rows' part (split forms); the paired form's instance carries none of that code
+// (fewer registers: more blocks in flight when there are many chains).
 constexpr int DELTA_THREADS = 256;   // k_move_delta: 4 waves, 2 rows each (8 waves and 4-row blocks measured slower)
+template <bool OWN>
 __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int buf,
                                                     int apply_f) {
     __shared__ Move mvA, mvB;
@@ -1421,7 +1424,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
         }
         DSTAMP(2);
         // paired form (apply_f): k_move_pair's workgroups have the updated rows' part already (Chains::Down)
-        if (!apply_f) own_rows_delta<DELTA_THREADS>(d, c, w, b, mv, psi, r_lo, r_hi, ltab, dth, dcn);
+        if (OWN) own_rows_delta<DELTA_THREADS>(d, c, w, b, mv, psi, r_lo, r_hi, ltab, dth, dcn);
     }
     DSTAMP(3);
     dth = wave_sum(dth);

@@ -1048,7 +1048,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                     hipLaunchKernelGGL(k_move_pair, dim3(2 * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
                                        have_prev, pbuf, nb, 2 * scan + half, s->pair_debug);
                     pbuf ^= 1;
-                    hipLaunchKernelGGL(k_move_delta, gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
+                    hipLaunchKernelGGL((k_move_delta<false>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
                 }
             if (have_prev) {
@@ -1069,7 +1069,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                         hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
                                            have_prev, pbuf);
                     pbuf ^= 1;
-                    hipLaunchKernelGGL(k_move_delta, gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 0);
+                    hipLaunchKernelGGL((k_move_delta<true>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 0);
                     have_prev = 1;
                 }
             if (have_prev) {
