@@ -1309,6 +1309,12 @@ __global__ __launch_bounds__(256) void k_apply_fpend(Dims d, Consts c, Work w, S
     apply_f_band<4>(d, c, w, b, fp, bx * rows_per_blk, min(d.M, (bx + 1) * rows_per_blk));
 }
 
+// rarely taken branch of band_delta, kept out of line so that its libm calls do not set the register
+// budget of the band kernel
+__device__ __attribute__((noinline)) double log1mexp_diff_slow(double r1, double r0, const double2 *ltab) {
+    return log1mexp(r1, ltab) - log1mexp(r0, ltab);
+}
+
 // Change of the S->E term of a cell whose F moves by dF while its own state is unchanged:
 //   k [L(r1) - L(r0)] - (S-k)(r1 - r0),  L(r) = log(1-exp(-r)),  r1 = r0 + a.
 // In the small-rate regime L(r1)-L(r0) = log(r1/r0) + g(r1) - g(r0) with log(r1/r0) = 2 atanh(z),
@@ -1333,7 +1339,7 @@ __device__ __forceinline__ double band_delta(double S, double I, double K0, doub
             const double g1 = r1 * (-0.5 + r1 * (4.1666666666666664e-2 - b2 * (3.4722222222222224e-4 - b2 * (5.5114638447971785e-6 - b2 * 1.0333994708994709e-7))));
             dL = at + (g1 - g0);
         } else {
-            dL = log1mexp(r1, ltab) - log1mexp(r0, ltab);
+            dL = log1mexp_diff_slow(r1, r0, ltab);
         }
         out += K0 * dL;
     }
