@@ -88,6 +88,7 @@ _SIGNATURES = {
     "seir_time_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.POINTER(ctypes.c_float)]),
     "seir_selftest_math": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [c_double_p] * 4),
+    "seir_selftest_math_wide": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [c_double_p] * 3),
     "seir_reproduction_number": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
     "seir_within_between": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_double,
                                            c_double_p, c_double_p]),

@@ -108,6 +108,36 @@ __device__ __forceinline__ void l1me_inv(double r, double &L, double &inv, const
         inv = e / om;
     }
 }
+// The same pair for rates that are not small: the I->R rate exp(gamma0 + gamma1 wd) is ~0.25-0.5 per
+// day, beyond the 4-term range above, and the libm branch (exp, log, divide: ~400 instructions) would be
+// taken by every lane of the single-wave HMC kernels.  8 Bernoulli terms reach r <= 3/4 at < 1e-16:
+//   log((1-e^-r)/r) = -r/2 + sum_n B_2n r^2n / (2n (2n)!),   1/expm1(r) = 1/r - 1/2 + sum_n B_2n r^(2n-1) / (2n)!
+constexpr double L1ME_WIDE_MAX = 0.75;
+__device__ __forceinline__ void l1me_inv_wide(double r, double &L, double &inv, const double2 *tab) {
+    if (r >= L1ME_SERIES_MIN && r <= L1ME_WIDE_MAX) {
+        const double r2 = r * r, ri = fast_rcp(r);
+        double pl = fma(r2, -2.1185501852016143e-14, 9.5589546647747706e-13);
+        pl = fma(r2, pl, -4.4034917822395777e-11);
+        pl = fma(r2, pl, 2.0876756987868099e-9);
+        pl = fma(r2, pl, -1.0333994708994709e-7);
+        pl = fma(r2, pl, 5.5114638447971785e-6);
+        pl = fma(r2, pl, -3.4722222222222224e-4);
+        pl = fma(r2, pl, 4.1666666666666664e-2);
+        L = fast_log(r, tab) + r * (-0.5 + r * pl);
+        double pi = fma(r2, -3.3896802963225829e-13, 1.3382536530684679e-11);
+        pi = fma(r2, pi, -5.2841901386874932e-10);
+        pi = fma(r2, pi, 2.0876756987868099e-8);
+        pi = fma(r2, pi, -8.2671957671957672e-7);
+        pi = fma(r2, pi, 3.3068783068783071e-5);
+        pi = fma(r2, pi, -1.3888888888888889e-3);
+        pi = fma(r2, pi, 8.3333333333333329e-2);
+        inv = ri - 0.5 + r * pi;
+    } else {
+        const double e = exp(-r), om = 1.0 - e;
+        L = log(om);
+        inv = e / om;
+    }
+}
 __device__ __forceinline__ double log1mexp(double r, const double2 *tab) {
     if (r >= L1ME_SERIES_MIN && r <= L1ME_SERIES_MAX) {
         const double r2 = r * r;

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         if (t < T) {
             const double r = rate[k] * d.dt;
             double L, inv;
-            l1me_inv(r, L, inv, ltab);
+            l1me_inv_wide(r, L, inv, ltab);
             rv[0] += (kir[k] != 0.0 ? kir[k] * L : 0.0) - dir[k] * r;
             const double gr = d.dt * ((kir[k] != 0.0 ? kir[k] * inv : 0.0) - dir[k]);
             rv[1] += gr * rate[k];
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
             const int tt = j * WAVE + lane;
             if (j < ntc && tt < T) {
                 double L, inv;
-                l1me_inv(ratev[j] * d.dt, L, inv, ltab);
+                l1me_inv_wide(ratev[j] * d.dt, L, inv, ltab);
                 const double grr = d.dt * ((kirv[j] != 0.0 ? kirv[j] * inv : 0.0) - dirv[j]);
                 gg0 += grr * ratev[j];
                 gg1 += grr * ratev[j] * wdv[j];

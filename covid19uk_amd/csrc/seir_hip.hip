@@ -513,6 +513,33 @@ struct DevBuf {
 };
 }  // namespace
 
+__global__ void k_selftest_math_wide(Consts c, int n, const double *x, double *L, double *inv) {
+    __shared__ double2 ltab[LDSTAB_N];
+    log_table_to_lds(ltab, c.logtab);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double a, b2;
+        l1me_inv_wide(x[i], a, b2, ltab);
+        L[i] = a; inv[i] = b2;
+    }
+}
+
+extern "C" int seir_selftest_math_wide(seir_ctx *ctx, int32_t n, const double *x, double *L, double *inv) {
+    int rc = check_batch(ctx, 1);
+    if (rc) return rc;
+    if (n < 1 || !x || !L || !inv) return fail(SEIR_ERR_INVALID, "bad arguments");
+    DevBuf dx, dL, di;
+    if ((rc = dx.alloc(sizeof(double) * n)) || (rc = dL.alloc(sizeof(double) * n)) || (rc = di.alloc(sizeof(double) * n)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_math_wide, dim3(64), dim3(256), 0, ctx->stream, ctx->c, n, dx.as<double>(), dL.as<double>(),
+                       di.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(L, dL.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(inv, di.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 extern "C" int seir_within_between(seir_ctx *ctx, int32_t n, const double *psi, const double *I_last, double W,
                                    double *within, double *between) {
     int rc = check_batch(ctx, 1);

@@ -153,6 +153,13 @@ class SeirModel:
         _lib.check(self._lib.seir_selftest_math(self._ctx, x.size, _dptr(x), _dptr(L), _dptr(inv), _dptr(lf)))
         return L, inv, lf
 
+    def selftest_math_wide(self, x):
+        """Device values of log(1-exp(-x)), 1/expm1(x) from the 8-term series (l1me_inv_wide)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        L, inv = np.empty_like(x), np.empty_like(x)
+        _lib.check(self._lib.seir_selftest_math_wide(self._ctx, x.size, _dptr(x), _dptr(L), _dptr(inv)))
+        return L, inv
+
     def within_between(self, psi, I_last, W):
         """(within, between) fractions [n,M] of the infection pressure of the last state
         (covid19uk/posterior/within_between.py:13-57).  psi [n], I_last [n,M], W scalar."""

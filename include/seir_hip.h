@@ -125,6 +125,8 @@ int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t iters, flo
  * for each x[i] > 0 returns L[i] = log(1-exp(-x)), inv[i] = 1/expm1(x) and
  * lfact[i] = log Gamma(floor(x)+1) as the kernels evaluate them.  Host pointers. */
 int seir_selftest_math(seir_ctx *ctx, int32_t n, const double *x, double *L, double *inv, double *lfact);
+/* the 8-term variant used where rates are not small (the I->R terms of the HMC kernels): L, inv as above */
+int seir_selftest_math_wide(seir_ctx *ctx, int32_t n, const double *x, double *L, double *inv);
 
 
 /* ------------------------------------------------------------------------

@@ -98,7 +98,10 @@ def test_series_constants():
     text = open(os.path.join(ROOT, "covid19uk_amd", "csrc", "device_math.h")).read()
     lits = sorted(set(float(x) for x in re.findall(r"\d\.\d{10,}e-\d+", text)))
     exact = sorted([1 / 24, 1 / 2880, 1 / 181440, 1 / 9676800, 1 / 12, 1 / 720, 1 / 30240, 1 / 1209600,
-                    1 / 12, 1 / 360, 1 / 1260, 1 / 1680, 1 / 3, 1 / 6, 1 / 7, 2.3190468138462996e-17])
+                    1 / 12, 1 / 360, 1 / 1260, 1 / 1680, 1 / 3, 1 / 6, 1 / 7, 2.3190468138462996e-17] +
+                   # Bernoulli terms 5..8 of l1me_inv_wide: |B_2n| / (2n (2n)!) and |B_2n| / (2n)!
+                   [float(abs(mp.bernoulli(2 * n)) / (2 * n * mp.factorial(2 * n))) for n in range(5, 9)] +
+                   [float(abs(mp.bernoulli(2 * n)) / mp.factorial(2 * n)) for n in range(5, 9)])
     for v in lits:
         assert min(abs(v - e) / e for e in exact) < 1e-15, v
     m = re.search(r"L1ME_SERIES_MAX = ([0-9.]+);", text)

@@ -193,6 +193,15 @@ def test_device_math_against_mpmath(Model):
         assert abs((mp.mpf(float(inv[i])) - it) / it) < 2e-15, (x[i], inv[i])
         lt = mp.loggamma(mp.floor(xi) + 1)
         assert abs(mp.mpf(float(lf[i])) - lt) <= 2e-15 * max(1, abs(lt)), (x[i], lf[i])
+    # the 8-term variant of the I->R terms (series up to 3/4, libm beyond)
+    xw = np.concatenate([np.linspace(1e-6, 0.75, 400), [0.125, 0.25, 0.2857, 0.75, 0.7500001, 2.0]])
+    with Model(case["cov"], case["init"]) as model:
+        Lw, iw = model.selftest_math_wide(xw)
+    for i in range(len(xw)):
+        xi = mp.mpf(float(xw[i]))
+        Lt, it = mp.log(1 - mp.e ** (-xi)), 1 / (mp.e ** xi - 1)
+        assert abs((mp.mpf(float(Lw[i])) - Lt) / Lt) < 2e-15 or abs(mp.mpf(float(Lw[i])) - Lt) < 2e-16, (xw[i], Lw[i])
+        assert abs((mp.mpf(float(iw[i])) - it) / it) < 2e-15, (xw[i], iw[i])
 
 
 def test_syn2048_matches_c_oracle(Model):
