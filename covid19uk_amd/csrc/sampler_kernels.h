@@ -579,7 +579,9 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             pr[0] += v * v;
             if (t < T) {
                 w.ea[(size_t)b * d.Tp + t] = exp(acc);
-                w.rir[(size_t)b * d.Tp + t] = exp(ng0 + ng1 * wdt[k]);
+                const double rnew = exp(ng0 + ng1 * wdt[k]);
+                w.rir[(size_t)b * d.Tp + t] = rnew;
+                if (STAGE == 0 && d.chunked) w.rirc[((size_t)b * 2 + 0) * d.Tp + t] = rnew;
             }
             if (STAGE == 0 && d.chunked) {
                 // hand-over to the chunked leapfrog steps: a_t, and per 64-day chunk (= one wave here)
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
             const bool on = j < ntc && tt < T;
             kirv[j] = on ? w.Kir[(size_t)b * d.Tp + tt] : 0.0;
             dirv[j] = on ? w.Dir[(size_t)b * d.Tp + tt] : 0.0;
-            ratev[j] = on ? w.rir[(size_t)b * d.Tp + tt] : 1.0;
+            ratev[j] = on ? w.rirc[((size_t)b * 2 + par) * d.Tp + tt] : 1.0;
             wdv[j] = on ? c.wd[tt] : 0.0;
         }
         lds_barrier();                                     // ltab (single wave: orders the LDS writes)
@@ -819,7 +821,9 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
         if (t < T) {
             w.acur[(size_t)b * d.Tp + t] = a_new;
             w.ea[(size_t)b * d.Tp + t] = exp(a_new);
-            w.rir[(size_t)b * d.Tp + t] = exp(g0n + g1n * wd_t);
+            const double rnew = exp(g0n + g1n * wd_t);
+            w.rir[(size_t)b * d.Tp + t] = rnew;            // read by nobody in this launch (the chunks read rirc[par])
+            w.rirc[((size_t)b * 2 + (par ^ 1)) * d.Tp + t] = rnew;
         }
         const double ca = wave_sum(an), cvp = wave_sum(v * pn), cva = wave_sum(v * an);
         if (lane == 0) {
