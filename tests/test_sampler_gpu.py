@@ -219,6 +219,32 @@ def test_pair_kernel_handshake_paths(api, monkeypatch, hook):
     _compare(tr, oracles, n, B, CFG_SMALL)
 
 
+@pytest.mark.parametrize("name,B,n,eps", [("uk380", 8, 40, 1.5e-5), ("micro_17x70", 5, 40, 0.0004)])
+def test_repeated_runs_are_bitwise_identical(api, name, B, n, eps):
+    """Nothing orders the workgroups of a launch, so any read of something another workgroup of the same
+    launch writes shows up as run-to-run variation: eight repeats of the same sweeps must agree bit
+    for bit (continuous quantities included)."""
+    SeirModel, ChainSampler = api
+    case = H.build_case(name, 31, alpha_t_sd=0.005)
+    u, ev = _start(case, B, 31, scale=0.002 if name == "uk380" else 0.05)
+    cfg = CFG_REF if name == "uk380" else CFG_SMALL
+    ref = None
+    for rep in range(8):
+        with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+            with ChainSampler(model, cfg, B, seed=8, trace_capacity=n) as s:
+                s.set_state(u, ev)
+                s.set_kernel(step_size=eps)
+                tr = s.sample(n)
+                _, _, lp = s.get_state()
+        got = (tr.theta.copy(), tr.events.copy(), tr.hmc["target_log_prob"].copy(), lp.copy(),
+               np.stack([tr.moves[k]["target_log_prob"] for k in sorted(tr.moves)]))
+        if ref is None:
+            ref = got
+        else:
+            for a, b_ in zip(ref, got):
+                assert np.array_equal(a, b_), rep
+
+
 def test_paired_and_split_launch_forms_agree_at_uk380(api, monkeypatch):
     """The paired form (k_move_pair: S->E updates inside the proposing workgroup, speculative E->I
     proposal certified by row comparison, deferred F band) against one-kernel-per-update on the
