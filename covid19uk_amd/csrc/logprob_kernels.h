@@ -37,6 +37,7 @@ struct Dims {
     int chunked;            // sampler: k_se also writes the tile scalars of the chunked leapfrog (Work::TS):
                             // 1 = column scalars only (the M-chunks sum the row partials themselves), 2 = all four
     int sp_par;             // which of the two Work::sp / Work::gst buffers holds the current position
+    int skew;               // test hook (SEIR_DEBUG_SKEW = 1..3): a third of the workgroups of every launch starts ~30 us late
     int aff_nb;             // 0 = natural grids (tile, chain); > 0 = 1-D grids of tiles*aff_nb blocks with chain <-> XCD affinity
     double nu, dt, rate_floor, car_half_logdet;
     double L_ei;            // log(1 - exp(-nu dt))
@@ -383,6 +384,15 @@ __global__ __launch_bounds__(256) void k_params(Dims d, Consts c, Work w, const 
 // ---------------------------------------------------------------------------
 constexpr int SE_RS = 72;       // LDS row stride (doubles) of the row-sum transpose: conflict-free b64 reads
 
+// Test hook: delays a pseudo-random third of the workgroups of a launch.  Results must not depend on it
+// (tests/test_sampler_gpu.py): nothing may be read that another workgroup of the same launch writes.
+__device__ __forceinline__ void debug_skew(const Dims &d) {
+    if (d.skew == 0) return;
+    const unsigned id = blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u;
+    if (((id * 2654435761u) >> 16) % 3u == (unsigned)(d.skew - 1))
+        for (int i = 0; i < 10; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // Chain <-> XCD affinity (speed only, never correctness): workgroups are dealt round-robin over
 // the 8 XCDs, so blocks L and L+8 share one.  With at most 8 chains in a launch every block of a
 // chain gets an id with the same L % 8, and so do the chain's single-workgroup kernels (block
@@ -413,6 +423,7 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     __shared__ double rowbuf[GRAD ? 4 * SE_RW * SE_RS : 1];
     __shared__ double rlbuf[4][WAVE], rsbuf[4][WAVE];
     __shared__ double2 ltab[LDSTAB_N];
+    debug_skew(d);
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (d.aff_nb > 0) {
         int tile;

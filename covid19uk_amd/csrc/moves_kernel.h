@@ -811,6 +811,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     __shared__ Move pendA, pendB;
     __shared__ double2 ltab[LDSTAB_N];
     __shared__ int s_sel, s_acc_se, s_conf, s_late;
+    debug_skew(d);
     const int role = blockIdx.x / nbk;
     const int b = d.b0 + (int)blockIdx.x - role * nbk, tid = threadIdx.x;
     const int M = d.M, T = d.T;

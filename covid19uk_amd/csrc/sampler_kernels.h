@@ -712,6 +712,7 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
     const int T = d.T, M = d.M, nmt = d.nmt;
     const int ntc = NTC > 0 ? NTC : d.ntc;
     const int ntile = nmt * ntc;
+    debug_skew(d);
     int bx = blockIdx.x, by = blockIdx.y;
     if (d.aff_nb > 0) xcd_affine(blockIdx.x, ntc + d.Mp / WAVE, d.aff_nb, by, bx);
     const int b = d.b0 + by, lane = threadIdx.x;
@@ -1303,6 +1304,7 @@ __device__ __forceinline__ void apply_f_band(const Dims &d, const Consts &c, con
 // the others on its way in).  grid (nrb_d, B).
 __global__ __launch_bounds__(256) void k_apply_fpend(Dims d, Consts c, Work w, SamplerCfg s, Chains ch) {
     __shared__ Move fp;
+    debug_skew(d);
     int bx = blockIdx.x, by = blockIdx.y;
     if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
     const int b = d.b0 + by;
@@ -1365,6 +1367,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
     __shared__ Move mvA, mvB;
     __shared__ int mv_sel;
     __shared__ Move fp;
+    debug_skew(d);
     constexpr int NW = DELTA_THREADS / WAVE;
     __shared__ double sh_th[NW], sh_cn[NW];
     __shared__ double2 ltab[LDSTAB_N];

@@ -1012,6 +1012,10 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     group_range(s, g, b0, nb);
     LaunchCfg l{ctx->d, s->gstream[g], nb, affinity_enabled()};
     l.d.b0 = b0;
+    {
+        const char *e = getenv("SEIR_DEBUG_SKEW");
+        l.d.skew = e ? atoi(e) : 0;
+    }
     const Dims d0 = l.d;
     hipStream_t st = l.st;
     // [part 0] HMC on u | events: L+1 gradient evaluations

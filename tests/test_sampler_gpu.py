@@ -245,6 +245,33 @@ def test_repeated_runs_are_bitwise_identical(api, name, B, n, eps):
                 assert np.array_equal(a, b_), rep
 
 
+@pytest.mark.parametrize("name,B,n,eps", [("uk380", 8, 25, 1.5e-5), ("micro_17x70", 5, 25, 0.0004), ("ni11", 2, 25, 0.002)])
+def test_results_do_not_depend_on_workgroup_timing(api, monkeypatch, name, B, n, eps):
+    """SEIR_DEBUG_SKEW delays a pseudo-random third of the workgroups of every launch by ~30 us -- longer
+    than any kernel of the sweep runs -- so a workgroup that reads what another one of the same launch
+    writes gets the other version.  All three thirds against the undisturbed run, bit for bit."""
+    SeirModel, ChainSampler = api
+    case = H.build_case(name, 33, alpha_t_sd=0.005)
+    u, ev = _start(case, B, 33, scale=0.002 if name == "uk380" else 0.05)
+    cfg = CFG_REF if name != "micro_17x70" else CFG_SMALL
+    ref = None
+    for skew in ("0", "1", "2", "3"):
+        monkeypatch.setenv("SEIR_DEBUG_SKEW", skew)
+        with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+            with ChainSampler(model, cfg, B, seed=8, trace_capacity=n) as s:
+                s.set_state(u, ev)
+                s.set_kernel(step_size=eps)
+                tr = s.sample(n)
+                _, _, lp = s.get_state()
+        got = (tr.theta.copy(), tr.events.copy(), tr.hmc["target_log_prob"].copy(), lp.copy(),
+               np.stack([tr.moves[k]["target_log_prob"] for k in sorted(tr.moves)]))
+        if ref is None:
+            ref = got
+        else:
+            for a, b_ in zip(ref, got):
+                assert np.array_equal(a, b_), skew
+
+
 def test_paired_and_split_launch_forms_agree_at_uk380(api, monkeypatch):
     """The paired form (k_move_pair: S->E updates inside the proposing workgroup, speculative E->I
     proposal certified by row comparison, deferred F band) against one-kernel-per-update on the
