@@ -450,6 +450,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
     __shared__ double2 ltab[LOGTAB_N];
     __shared__ int s_acc;
     __shared__ double s_dth, s_dcn;
+    debug_skew(d);
     int bx = blockIdx.x, by = blockIdx.y;
     if (d.aff_nb > 0) xcd_affine(blockIdx.x, s.nrb_d, d.aff_nb, by, bx);
     const int b = d.b0 + by, tid = threadIdx.x;

@@ -1545,6 +1545,7 @@ __global__ __launch_bounds__(256) void k_move_pa(Dims d, Consts c, Work w, Sampl
 // lanes over days (coalesced plane reads, no index division); grid (ceil(M/4), B).
 // `advanced`: the sweep counter was already incremented by the closing k_move_pa2.
 __global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Chains ch, int advanced) {
+    debug_skew(d);
     const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + wave;
     const unsigned slot = ch.sweep[b] - (unsigned)advanced - ch.slot0[0];

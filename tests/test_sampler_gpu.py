@@ -245,12 +245,15 @@ def test_repeated_runs_are_bitwise_identical(api, name, B, n, eps):
                 assert np.array_equal(a, b_), rep
 
 
+@pytest.mark.parametrize("forms", ["chunk,paired", "single,split"])
 @pytest.mark.parametrize("name,B,n,eps", [("uk380", 8, 25, 1.5e-5), ("micro_17x70", 5, 25, 0.0004), ("ni11", 2, 25, 0.002)])
-def test_results_do_not_depend_on_workgroup_timing(api, monkeypatch, name, B, n, eps):
+def test_results_do_not_depend_on_workgroup_timing(api, monkeypatch, name, B, n, eps, forms):
     """SEIR_DEBUG_SKEW delays a pseudo-random third of the workgroups of every launch by ~30 us -- longer
     than any kernel of the sweep runs -- so a workgroup that reads what another one of the same launch
     writes gets the other version.  All three thirds against the undisturbed run, bit for bit."""
     SeirModel, ChainSampler = api
+    monkeypatch.setenv("SEIR_HMC", forms.split(",")[0])
+    monkeypatch.setenv("SEIR_MOVES", forms.split(",")[1])
     case = H.build_case(name, 33, alpha_t_sd=0.005)
     u, ev = _start(case, B, 33, scale=0.002 if name == "uk380" else 0.05)
     cfg = CFG_REF if name != "micro_17x70" else CFG_SMALL
