@@ -44,6 +44,15 @@ struct Dims {
     double prior_const;     // parameter-free part of the summed prior log-densities
 };
 
+// Test hook: delays a pseudo-random third of the workgroups of a launch.  Results must not depend on it
+// (tests/test_sampler_gpu.py): nothing may be read that another workgroup of the same launch writes.
+__device__ __forceinline__ void debug_skew(const Dims &d) {
+    if (d.skew == 0) return;
+    const unsigned id = blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u;
+    if (((id * 2654435761u) >> 16) % 3u == (unsigned)(d.skew - 1))
+        for (int i = 0; i < 10; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 struct Consts {
     const double *Cstar;   // [Mp][Kp0], Kp0 = Mp: zero-padded, symmetric
     const double *N, *invN, *la;   // [Mp]
@@ -97,6 +106,7 @@ template <int SRC>
 __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
     extern __shared__ double lds[];                 // [SCAN_WAVES][Tp][2]
     __shared__ double2 ltab[LDSTAB_N];
+    debug_skew(d);
     const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *mycol = lds + (size_t)wave * d.Tp * 2;
     for (int i = lane; i < d.Tp * 2; i += WAVE) mycol[i] = 0.0;
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Wo
 __global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) {
     __shared__ double sh[4];
     __shared__ double2 part[4][WAVE];
+    debug_skew(d);
     const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * WAVE + lane;
     // wave w folds the partial rows rb = w, w+4, ...; 16 loads in flight per batch
@@ -241,6 +252,7 @@ __host__ __device__ inline size_t gemm_lds_bytes() { return (size_t)2 * GEMM_KC 
 
 __global__ __launch_bounds__(256) void k_gemm(Dims d, Consts c, Work w) {
     extern __shared__ double lds[];                 // [A | B][KC][RS]
+    debug_skew(d);
     const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * GEMM_TM, t0 = blockIdx.x * GEMM_TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
@@ -383,15 +395,6 @@ __global__ __launch_bounds__(256) void k_params(Dims d, Consts c, Work w, const 
 // contribute exactly zero, so there are no bounds masks.
 // ---------------------------------------------------------------------------
 constexpr int SE_RS = 72;       // LDS row stride (doubles) of the row-sum transpose: conflict-free b64 reads
-
-// Test hook: delays a pseudo-random third of the workgroups of a launch.  Results must not depend on it
-// (tests/test_sampler_gpu.py): nothing may be read that another workgroup of the same launch writes.
-__device__ __forceinline__ void debug_skew(const Dims &d) {
-    if (d.skew == 0) return;
-    const unsigned id = blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u;
-    if (((id * 2654435761u) >> 16) % 3u == (unsigned)(d.skew - 1))
-        for (int i = 0; i < 10; ++i) __builtin_amdgcn_s_sleep(127);
-}
 
 // Chain <-> XCD affinity (speed only, never correctness): workgroups are dealt round-robin over
 // the 8 XCDs, so blocks L and L+8 share one.  With at most 8 chains in a launch every block of a

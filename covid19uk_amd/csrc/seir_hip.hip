@@ -270,7 +270,12 @@ static int affinity_enabled() {
     const char *e = getenv("SEIR_XCD_AFFINITY");     // read per call: launches are enqueued at graph capture
     return e ? atoi(e) : 3;
 }
-static LaunchCfg whole(seir_ctx *ctx, int B) { return LaunchCfg{ctx->d, ctx->stream, B, affinity_enabled()}; }
+static LaunchCfg whole(seir_ctx *ctx, int B) {
+    LaunchCfg l{ctx->d, ctx->stream, B, affinity_enabled()};
+    const char *e = getenv("SEIR_DEBUG_SKEW");          // test hook, see debug_skew()
+    l.d.skew = e ? atoi(e) : 0;
+    return l;
+}
 
 template <int SRC>
 static void launch_scan(seir_ctx *ctx, const LaunchCfg &l, const double *events) {
