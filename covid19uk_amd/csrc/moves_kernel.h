@@ -217,22 +217,31 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
         const int tper = (T + MVB - 1) / MVB;
         const int t_lo = tid * tper, t_hi = min(T, t_lo + tper);
         int Dj[MMAX], tj[MMAX];
-        for (int j = 0; j < nsel; ++j) {
-            const int *kr = L.rk + j * T1;
-            int cc = 0;
-            for (int t = t_lo; t < t_hi; ++t) cc += kr[t] > 0 ? 1 : 0;
-            int D;
-            const int bef = mv_excl_scan(cc, sm.ired, D);
-            const int r = rng_index(sm.u[2 * j][1], D);
-            if (r >= bef && r < bef + cc) {
-                int k = r - bef;
-                for (int t = t_lo; t < t_hi; ++t)
-                    if (kr[t] > 0) {
-                        if (k == 0) { sm.sel[j] = (sm.sel[j] & 0xffff) | (t << 16); break; }
-                        --k;
-                    }
+        // two rows per scan: the counts (<= T <= 1024) travel in the two halves of one int
+        for (int j0 = 0; j0 < nsel; j0 += 2) {
+            const bool two = j0 + 1 < nsel;
+            const int *k0 = L.rk + j0 * T1, *k1 = L.rk + (two ? j0 + 1 : j0) * T1;
+            int c0 = 0, c1 = 0;
+            for (int t = t_lo; t < t_hi; ++t) { c0 += k0[t] > 0 ? 1 : 0; c1 += (two && k1[t] > 0) ? 1 : 0; }
+            int Dp;
+            const int befp = mv_excl_scan(c0 | (c1 << 16), sm.ired, Dp);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two) break;
+                const int j = j0 + h;
+                const int *kr = h ? k1 : k0;
+                const int cc = h ? c1 : c0, bef = h ? (befp >> 16) : (befp & 0xffff), D = h ? (Dp >> 16) : (Dp & 0xffff);
+                const int r = rng_index(sm.u[2 * j][1], D);
+                if (r >= bef && r < bef + cc) {
+                    int k = r - bef;
+                    for (int t = t_lo; t < t_hi; ++t)
+                        if (kr[t] > 0) {
+                            if (k == 0) { sm.sel[j] = (sm.sel[j] & 0xffff) | (t << 16); break; }
+                            --k;
+                        }
+                }
+                Dj[j] = D;
             }
-            Dj[j] = D;
         }
         lds_barrier();
         MSTAMP(7);
