@@ -275,6 +275,32 @@ def test_results_do_not_depend_on_workgroup_timing(api, monkeypatch, name, B, n,
                 assert np.array_equal(a, b_), skew
 
 
+@pytest.mark.parametrize("name,cfg,eps", [("micro_5x24", CFG_SMALL, 0.002), ("micro_2x2", CFG_SMALL, 0.002),
+                                          ("ni11", CFG_REF, 0.002)])
+def test_paired_and_split_agree_over_many_sweeps_with_frequent_conflicts(api, monkeypatch, name, cfg, eps):
+    """Few rows: the speculative E->I proposal collides with the updates accepted before it in a large
+    share of the launches, so the re-draw path and every certification rule run hundreds of times."""
+    SeirModel, ChainSampler = api
+    case = H.build_case(name, 41, alpha_t_sd=0.005)
+    B, n = 4, 300
+    u, ev = _start(case, B, 41)
+    out = {}
+    for mode in ("paired", "split"):
+        monkeypatch.setenv("SEIR_MOVES", mode)
+        with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+            with ChainSampler(model, cfg, B, seed=5, trace_capacity=n) as s:
+                s.set_state(u, ev)
+                s.set_kernel(step_size=eps)
+                out[mode] = s.sample(n)
+    a, b_ = out["paired"], out["split"]
+    assert np.array_equal(a.events, b_.events)
+    for key in a.moves:
+        assert np.array_equal(a.moves[key]["proposed_delta"], b_.moves[key]["proposed_delta"]), key
+        assert np.array_equal(a.moves[key]["is_accepted"], b_.moves[key]["is_accepted"]), key
+    assert np.array_equal(a.hmc["is_accepted"], b_.hmc["is_accepted"])
+    assert sum(int(a.moves[k]["is_accepted"].sum()) for k in a.moves) > 200
+
+
 def test_paired_and_split_launch_forms_agree_at_uk380(api, monkeypatch):
     """The paired form (k_move_pair: S->E updates inside the proposing workgroup, speculative E->I
     proposal certified by row comparison, deferred F band) against one-kernel-per-update on the
