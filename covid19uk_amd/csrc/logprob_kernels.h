@@ -524,11 +524,16 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
     } else if (GRAD && wave == 2) {
         const double cs = (colbuf[0][lane] + colbuf[1][lane]) + (colbuf[2][lane] + colbuf[3][lane]);
         w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t] = cs;
-        if (ts_on) {
+        if (ts_on && ts_rows) {                            // TSM 2: wave 3 is busy with the row scalars
             const double bs = wave_sum(cs), as = wave_sum(cs * ts_vt);
             if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
         }
     } else if (GRAD && wave == 3) {
+        if (ts_on && !ts_rows) {                           // TSM 1: the column scalars beside wave 2's store
+            const double cs = (colbuf[0][lane] + colbuf[1][lane]) + (colbuf[2][lane] + colbuf[3][lane]);
+            const double bs = wave_sum(cs), as = wave_sum(cs * ts_vt);
+            if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
+        }
         if (ts_rows) {
             const double rl = wave_sum((rlbuf[0][lane] + rlbuf[1][lane]) + (rlbuf[2][lane] + rlbuf[3][lane]));
             const double rs = wave_sum((rsbuf[0][lane] + rsbuf[1][lane]) + (rsbuf[2][lane] + rsbuf[3][lane]));
