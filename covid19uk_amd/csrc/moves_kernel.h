@@ -108,7 +108,6 @@ __device__ __forceinline__ void mv_sum2(double &a, double &b2, double *sh) {
 // arrays the proposal works from
 struct MvLds {
     const int *rt;         // [M] row totals of the target transition's events (LDS copy, patched)
-    int rstride;           // unused (kept for the layout of the first implementation)
     int *rg;               // [M] events of the target transition inside the occult range (LDS)
     int *rk, *rsrc, *rdst; // [MMAX][T+1] staged rows (LDS): target events, compartments either side at start of day
 #ifdef SEIR_STAMPS
@@ -591,7 +590,6 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
         MvLds L{};
         int *rtl = dyn_i + M;
         L.rt = rtl;
-        L.rstride = 0;
         L.rg = dyn_i;
         L.rk = dyn_i + 2 * M;
         L.rsrc = L.rk + MMAX * (T + 1);
@@ -864,7 +862,6 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     MvLds L{};
     int *rtl = dyn_i + M;
     L.rt = rtl;
-    L.rstride = 0;
     L.rg = dyn_i;
     L.rk = dyn_i + 2 * M;
     L.rsrc = L.rk + MMAX * (T + 1);

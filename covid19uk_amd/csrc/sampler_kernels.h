@@ -1192,16 +1192,9 @@ __device__ inline void propose(const Dims &d, const Work &w, const SamplerCfg &s
     if (tid == 0) ch.mv[(size_t)nbuf * s.B + b] = mv;
 }
 
-// Per-cell log-likelihood pieces: th = parameter dependent (S->E and I->R
-// rates), cn = parameter free (binomial coefficients + E->I term).
-__device__ inline void cell_terms(const Dims &d, double S, double E, double I, double kse, double kei, double kir,
-                                  double F, double ee, double psiW, double r_ir, double L_ir, double L_ei,
-                                  double r_ei, const double2 *ltab, double &th, double &cn) {
-    cn = lbinom(S, kse, ltab) + lbinom(E, kei, ltab) + lbinom(I, kir, ltab) + kei * L_ei - (E - kei) * r_ei;
-    const double rr = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
-    th = (kse != 0.0 ? kse * log1mexp(rr, ltab) : 0.0) - (S - kse) * rr;
-    th += (kir != 0.0 ? kir * L_ir : 0.0) - (I - kir) * r_ir;
-}
+// Per-cell log-likelihood pieces (the full form the differences below are taken from):
+//   cn = lbinom(S,k_se) + lbinom(E,k_ei) + lbinom(I,k_ir) + k_ei L_ei - (E - k_ei) r_ei       (parameter free)
+//   th = k_se log(1 - e^-rr) - (S - k_se) rr + k_ir L_ir - (I - k_ir) r_ir,  rr = (ee (I + psi W F) + floor) dt
 
 // Log-ratio contribution of the rows a proposal updates (their own state and events change, and
 // for E->I updates F moves as well): sum over the touched days of [terms(new) - terms(old)].
@@ -1255,7 +1248,7 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
                     if (i < fp->n && t > fp->lo[i] && t <= fp->hi[i]) F += cfp[i];
             }
             const double ee = ea[t] * eb, psiW = psi * c.W[t];
-            // only the terms the update changes (cell_terms(new) - cell_terms(old) with the rest cancelled):
+            // only the terms the update changes (terms(new) - terms(old) with the rest cancelled):
             // 4 instead of 6 binomial coefficients, no I->R log
             const double rr0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
             if (mv.tgt == 0) {
