@@ -96,6 +96,33 @@ def test_fixed_kernel_sweeps_match_oracle(api, monkeypatch, name, cfg, seed, eps
             assert any(tr.moves[k]["is_accepted"].any() for k in tr.moves)
 
 
+@pytest.mark.parametrize("name,cfg,eps", [
+    ("micro_5x24", dict(dmax=3, nmax=1, m=1, occult_nmax=1, num_event_time_updates=1), 0.002),
+    ("micro_5x24", dict(dmax=20, nmax=10, m=4, occult_nmax=8, num_event_time_updates=2), 0.002),
+    ("micro_5x24", dict(dmax=8, nmax=6, m=3, occult_nmax=0, num_event_time_updates=2), 0.002),
+    ("micro_6x10", dict(dmax=30, nmax=4, m=2, occult_nmax=3, num_event_time_updates=3), 0.002),   # T < 21: whole series is the occult range; dmax > T
+    ("micro_3x70", dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=4), 0.001),  # more updates per row than rows
+])
+def test_move_configurations_match_oracle(api, name, cfg, eps):
+    """Corners of the Mcmc configuration (one or four metapopulations per update, no occults, a series
+    shorter than the occult window, dmax beyond the series) against the oracle, default launch forms."""
+    SeirModel, ChainSampler = api
+    case = H.build_case(name, 17, alpha_t_sd=0.005)
+    B, n = 2, 8
+    u, ev = _start(case, B, 17)
+    oracles = []
+    for b in range(B):
+        ch = mo.OracleChain(case["k"], cfg, u[b], ev[b], seed=9, chain_id=b)
+        ch.eps = eps
+        oracles.append([ch.sweep_once() for _ in range(n)])
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, cfg, B, seed=9, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=eps)
+            tr = s.sample(n)
+    _compare(tr, oracles, n, B, cfg)
+
+
 def test_adaptation_windows_match_oracle(api):
     """Dual averaging, then dual averaging + diagonal mass adaptation (the fast and slow
     windows of inference.py:60-196), compared step by step.  Each window restarts from the
