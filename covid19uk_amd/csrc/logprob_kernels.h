@@ -245,41 +245,55 @@ __global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) {
 // and lands in LDS already "transposed" for the A fragment; row stride 80 doubles (== 16 mod 32)
 // makes both fragment reads conflict-free ds_read_b64.
 // ---------------------------------------------------------------------------
-constexpr int GEMM_TM = 64, GEMM_TN = 64, GEMM_KC = 64, GEMM_RS = 80;
+constexpr int GEMM_TM = 64, GEMM_KC = 64, GEMM_RS = 80;
 using d4 = __attribute__((ext_vector_type(4))) double;
 
-__host__ __device__ inline size_t gemm_lds_bytes() { return (size_t)2 * GEMM_KC * GEMM_RS * sizeof(double); }
+// TN = 64: 4 waves (2 x 2), TN = 96: 6 waves (2 x 3) -- at Tp = 384 (UK) 36 tiles of 64 x 64 per chain
+// are 288 workgroups on 256 CUs, two rounds; 24 tiles of 64 x 96 are 192, one round with 1.5 waves
+// per SIMD.  The B panel's row stride is TN + 16 (== 16 mod 32 like the A panel's 80).
+template <int TN> __host__ __device__ constexpr int gemm_rsb() { return TN + 16; }
+template <int TN> __host__ __device__ constexpr int gemm_threads() { return (GEMM_TM / 32) * (TN / 32) * WAVE; }
+template <int TN>
+__host__ __device__ inline size_t gemm_lds_bytes() {
+    return (size_t)GEMM_KC * (GEMM_RS + gemm_rsb<TN>()) * sizeof(double);
+}
 
-__global__ __launch_bounds__(256) void k_gemm(Dims d, Consts c, Work w) {
-    extern __shared__ double lds[];                 // [A | B][KC][RS]
+template <int TN>
+__global__ __launch_bounds__(gemm_threads<TN>()) void k_gemm(Dims d, Consts c, Work w) {
+    extern __shared__ double lds[];                 // A [KC][RS] | B [KC][RSB]
+    constexpr int NT = gemm_threads<TN>(), RSB = gemm_rsb<TN>(), NWC = TN / 32;
     debug_skew(d);
-    const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * GEMM_TM, t0 = blockIdx.x * GEMM_TN;
+    const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * GEMM_TM, t0 = blockIdx.x * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / NWC, wc = wave % NWC;
     const double *Xb = w.Xn + (size_t)b * d.Mp * d.Tp;
     double *A = lds, *Bm = lds + GEMM_KC * GEMM_RS;
-    // staging: KC rows x 64 columns per matrix = KC*32 double2, KC/8 per thread and matrix
-    constexpr int NST = GEMM_KC / 8;
-    const int sr = tid >> 5, sc2 = (tid & 31) * 2;
-    double2 ra[NST], rb[NST];
+    // staging in double2 elements: A chunk KC x 64, B chunk KC x TN
+    constexpr int EA = GEMM_KC * (GEMM_TM / 2), EB = GEMM_KC * (TN / 2);
+    constexpr int NA = (EA + NT - 1) / NT, NB = (EB + NT - 1) / NT;
+    double2 ra[NA], rb[NB];
     auto load_chunk = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int k = kb + sr + 8 * i;
-            if (k < d.Kp) {
-                ra[i] = *(const double2 *)(c.Cstar + (size_t)k * d.Kp0 + m0 + sc2);
-                rb[i] = *(const double2 *)(Xb + (size_t)k * d.Tp + t0 + sc2);
-            } else {
-                ra[i] = make_double2(0.0, 0.0);
-                rb[i] = make_double2(0.0, 0.0);
-            }
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + i * NT, row = e / (GEMM_TM / 2), col = (e % (GEMM_TM / 2)) * 2, k = kb + row;
+            ra[i] = (e < EA && k < d.Kp) ? *(const double2 *)(c.Cstar + (size_t)k * d.Kp0 + m0 + col) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + i * NT, row = e / (TN / 2), col = (e % (TN / 2)) * 2, k = kb + row;
+            rb[i] = (e < EB && k < d.Kp) ? *(const double2 *)(Xb + (size_t)k * d.Tp + t0 + col) : make_double2(0.0, 0.0);
         }
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            *(double2 *)(A + (sr + 8 * i) * GEMM_RS + sc2) = ra[i];
-            *(double2 *)(Bm + (sr + 8 * i) * GEMM_RS + sc2) = rb[i];
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + i * NT, row = e / (GEMM_TM / 2), col = (e % (GEMM_TM / 2)) * 2;
+            if (e < EA) *(double2 *)(A + row * GEMM_RS + col) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + i * NT, row = e / (TN / 2), col = (e % (TN / 2)) * 2;
+            if (e < EB) *(double2 *)(Bm + row * RSB + col) = rb[i];
         }
     };
     d4 acc[2][2];
@@ -293,11 +307,11 @@ __global__ __launch_bounds__(256) void k_gemm(Dims d, Consts c, Work w) {
     __syncthreads();
     for (int kb = 0; kb < d.Kp; kb += GEMM_KC) {
         const bool more = kb + GEMM_KC < d.Kp;
-        if (more) load_chunk(kb + GEMM_KC);          // in flight behind the 64 MFMAs of this chunk
+        if (more) load_chunk(kb + GEMM_KC);          // in flight behind the MFMAs of this chunk
 #pragma unroll
         for (int kk = 0; kk < GEMM_KC; kk += 4) {
             const double *ap = A + (kk + ak) * GEMM_RS + wr * 32 + ar;
-            const double *bp = Bm + (kk + ak) * GEMM_RS + wc * 32 + ar;
+            const double *bp = Bm + (kk + ak) * RSB + wc * 32 + ar;
             const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);

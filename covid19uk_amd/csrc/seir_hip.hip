@@ -289,10 +289,25 @@ static void launch_scan(seir_ctx *ctx, const LaunchCfg &l, const double *events)
 static void launch_colreduce(seir_ctx *ctx, const LaunchCfg &l) {
     hipLaunchKernelGGL(k_colreduce, dim3(l.d.Tp / WAVE, l.nb), dim3(256), 0, l.st, l.d, ctx->w);
 }
-static void launch_gemm(seir_ctx *ctx, const LaunchCfg &l) {
+template <int TN>
+static void launch_gemm_t(seir_ctx *ctx, const LaunchCfg &l) {
     const Dims &d = l.d;
-    hipLaunchKernelGGL(k_gemm, dim3(d.Tp / GEMM_TN, d.Mp / GEMM_TM, l.nb), dim3(256), gemm_lds_bytes(), l.st, d,
-                       ctx->c, ctx->w);
+    const size_t lds = gemm_lds_bytes<TN>();
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_gemm<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm<TN>), dim3(d.Tp / TN, d.Mp / GEMM_TM, l.nb), dim3(gemm_threads<TN>()), lds, l.st, d, ctx->c,
+                       ctx->w);
+}
+static void launch_gemm(seir_ctx *ctx, const LaunchCfg &l) {
+    // 64 x 96 tiles only where they turn two rounds of workgroups into one (UK-380, 8 chains: 288 -> 192 on
+    // 256 CUs, 34.6 -> 32.9 us); on large grids the 6-wave tile loses to the 4-wave one (SYN-2048: 38.6 vs 51.7 TF)
+    const Dims &d = l.d;
+    const long t64 = (long)(d.Tp / 64) * (d.Mp / GEMM_TM) * l.nb, t96 = (long)(d.Tp / 96) * (d.Mp / GEMM_TM) * l.nb;
+    if (d.Tp % 96 == 0 && t64 > 256 && t96 <= 256) launch_gemm_t<96>(ctx, l);
+    else launch_gemm_t<64>(ctx, l);
 }
 static void launch_params(seir_ctx *ctx, const LaunchCfg &l, const double *u) {
     hipLaunchKernelGGL(k_params, dim3(l.nb), dim3(256), 0, l.st, l.d, ctx->c, ctx->w, u);
