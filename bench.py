@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 MCMC_CONFIG = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5)  # example_config.yaml:26-30
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, chip-level parameters
+F64_MFMA_PEAK_TFLOPS = 78.6     # dense fp64 matrix peak (v_mfma_f64_16x16x4_f64), same guide
 
 
 def parse():
@@ -46,18 +47,22 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chains-scaling", action="store_true",
                     help="skip the extra (untimed-by-the-contract) runs at 32 and 64 chains on this GPU")
-    ap.add_argument("--cpu-baseline-sweeps", type=int, default=0, help="0 = size for ~15 s")
+    ap.add_argument("--cpu-baseline-sweeps", type=int, default=0, help="0 = size for ~10 s per leg")
+    ap.add_argument("--spinup-seconds", type=float, default=0.7,
+                    help="untimed sweeps run back to back before the timed region so that a short --steps run is "
+                         "measured at steady clocks (a fresh box ramps for a few hundred ms)")
     ap.add_argument("--seed", type=int, default=20210101)
     return ap.parse_args()
 
 
-def cpu_baseline(cov, init, events, u0, n_sweeps, seed):
+def cpu_baseline(cov, init, events, u0, n_sweeps, seed, cores=None):
     """The oracle sampler (full re-evaluation of the joint log-prob for every proposal, as
     the reference does) on the host cores, C restatement of the density with OpenMP."""
     from oracle import c_binding, mcmc_oracle as mo, seir_oracle as so
     k = so.make_constants(cov.C, cov.N, cov.W, cov.weekday, cov.area, cov.adjacency, init)
     # the box's CPU share for one GPU is 16 cores; more OpenMP threads than that only add overhead
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    if cores is None:
+        cores = min(len(os.sched_getaffinity(0)), 16)
     c_binding.set_threads(cores)
     lp = lambda u, ev: c_binding.evaluate(k, u, ev, 1)                      # noqa: E731
     lpg = lambda u, ev: c_binding.evaluate(k, u, ev, 1, want_grad=True)     # noqa: E731
@@ -66,7 +71,7 @@ def cpu_baseline(cov, init, events, u0, n_sweeps, seed):
     t0 = time.perf_counter()
     ch.sweep_once()
     one = time.perf_counter() - t0
-    n = n_sweeps if n_sweeps > 0 else max(2, min(40, int(15.0 / max(one, 1e-3))))
+    n = n_sweeps if n_sweeps > 0 else max(2, min(40, int(10.0 / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
         ch.sweep_once()
@@ -142,6 +147,14 @@ def main():
     sampler.reset_trace()
     sampler.run(W)
     model.sync()
+    # spin-up (untimed): keep the GPU busy until it holds its steady clock; with the default
+    # --steps the timed region is only ~0.1 s and would otherwise sit on the clock ramp
+    spin_sweeps, t_spin = 0, time.perf_counter()
+    while time.perf_counter() - t_spin < a.spinup_seconds:
+        sampler.reset_trace()
+        sampler.run(min(max(K, 1), 100))
+        model.sync()
+        spin_sweeps += min(max(K, 1), 100)
     sampler.reset_trace()
     if world > 1:
         dist.barrier()
@@ -170,6 +183,11 @@ def main():
     M, T, P = cov.M, cov.T, model.P
     alg_bytes = B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
     achieved = alg_bytes / (grad_ms * 1e-3) / 1e9
+    # what this kernel itself moves: int32 k_se, S, I + fp64 F per padded cell (20 B), the per-row /
+    # per-day tables, and its partial sums out (row sums per day chunk, column sums per row tile, 4 tile scalars)
+    Mp, Tp = -(-M // 64) * 64, -(-T // 64) * 64
+    nmt, ntc = Mp // 16, Tp // 64
+    kernel_bytes = B * (20 * Mp * Tp + 8 * (Mp + 2 * Tp) + 8 * (ntc * Mp + nmt * Tp) + 8 * 6 * nmt * ntc)
     # HBM-side traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this
     # process): FETCH_SIZE x the gfx950 calibration factor + WRITE_SIZE, same workload and batch.
     traffic, traffic_src = None, None
@@ -177,7 +195,7 @@ def main():
     pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if a.workload == "uk380" and B == 8 and pmcs:
         doc = json.load(open(pmcs[-1]))
-        ent = doc.get("k_se<true, 1>") or doc.get("k_se<true,1>")
+        ent = doc.get("k_se<GRAD=true,SRC=planes>")
         if ent:
             traffic = ent["traffic_bytes_per_launch"]
             traffic_src = "profiles/" + os.path.basename(pmcs[-1])
@@ -208,6 +226,23 @@ def main():
         for _ in range(50):
             model.eval_prepared_dev(ut, lp, g)
         evals[name] = B * 50 / (model.timer_stop() * 1e-3)
+
+    # the stateless evaluation (what the reference calls 37x per draw) against ITS bound: the larger of the
+    # HBM time of the algorithmic bytes and the fp64 matrix time of the mobility contraction 2 M^2 T per chain
+    t_hbm = alg_bytes / (HBM_PEAK_GBPS * 1e9)
+    t_mfma = 2.0 * M * M * T * B / (F64_MFMA_PEAK_TFLOPS * 1e12)
+    t_eval = B / evals["value_and_grad"]
+    stateless = {"path": "seir_log_prob_dev, value + gradient (k_scan, k_colreduce, k_gemm, k_params, k_se, k_finish)",
+                 "bound": "mfma" if t_mfma > t_hbm else "hbm",
+                 "t_hbm_us": 1e6 * t_hbm, "t_mfma_us": 1e6 * t_mfma, "measured_us_per_batch": 1e6 * t_eval,
+                 "frac": max(t_hbm, t_mfma) / t_eval,
+                 "achieved": (2.0 * M * M * T * B / t_eval / 1e12) if t_mfma > t_hbm else alg_bytes / t_eval / 1e9,
+                 "peak": F64_MFMA_PEAK_TFLOPS if t_mfma > t_hbm else HBM_PEAK_GBPS,
+                 "unit": "TFLOP/s" if t_mfma > t_hbm else "GB/s"}
+    try:
+        stateless["kernels_us"] = {n: 1e3 * model.time_kernel(n, B, 50) for n in ("scan", "gemm", "se_grad", "finish")}
+    except Exception as e:                                  # timing hook only
+        stateless["kernels_us"] = str(e)
 
     # context for the headline number (N=1 only, not part of `value`): the same sweep with more
     # chains resident on this GPU -- at 8 chains the sweep is bound by its dependent-launch chain,
@@ -256,8 +291,14 @@ def main():
             "roofline": {"kernel": "k_se<GRAD=true,SRC=planes> (S->E term + gradient sums, all chains)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_uses": "algorithmic_bytes_per_launch (SURVEY.md 8d: fp64 events + Cstar once per launch)",
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": 1e3 * grad_ms,
+                         "kernel_bytes_per_launch": kernel_bytes,
+                         "frac_kernel_bytes": kernel_bytes / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "frac_traffic": (traffic / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "launches_per_sweep": 17},
+            "roofline_stateless": stateless,
+            "spinup_sweeps": spin_sweeps,
             "log_prob_evals_per_sec": evals,
             "hip_event_ms_per_step": ev_ms / K,
             "pcie_inclusive_samples_per_sec": world * B * K / (elapsed + d2h),
@@ -267,6 +308,7 @@ def main():
             out["chains_per_gpu_scaling"] = scaling
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed)
+            out["cpu_baseline_1core"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed, cores=1)
         print(json.dumps(out), flush=True)
     if scaling is None:
         sampler.close()

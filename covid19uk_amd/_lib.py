@@ -40,6 +40,10 @@ class SeirSamplerDesc(ctypes.Structure):
         ("num_leapfrog_steps", ctypes.c_int32), ("trace_capacity", ctypes.c_int32),
         ("first_chain_id", ctypes.c_int32), ("record_events", ctypes.c_int32),
         ("seed", ctypes.c_uint64),
+        # ABI v2: launch form and test hooks, all-zero = defaults
+        ("moves_mode", ctypes.c_int32), ("hmc_mode", ctypes.c_int32), ("use_graph", ctypes.c_int32),
+        ("chain_groups", ctypes.c_int32), ("disable_mask", ctypes.c_int32), ("debug_pair", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -56,6 +60,8 @@ class SeirSimDesc(ctypes.Structure):
     ]
 
 
+ABI_VERSION = 2               # SEIR_ABI_VERSION
+OPT_DEBUG_SKEW, OPT_XCD_AFFINITY = 0, 1
 MMAX = 4                      # SEIR_MMAX
 MOVE_TRACE = 2 + 4 * MMAX     # SEIR_MOVE_TRACE
 
@@ -79,6 +85,7 @@ _SIGNATURES = {
     "seir_eval_prepared_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 3),
     "seir_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "seir_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "seir_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]),
     "seir_malloc": (ctypes.c_int, [c_void_pp, ctypes.c_uint64]),
     "seir_free": (ctypes.c_int, [ctypes.c_void_p]),
     "seir_memcpy_h2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
@@ -111,6 +118,7 @@ _SIGNATURES = {
                                                ctypes.POINTER(ctypes.c_int32), c_double_p, c_double_p]),
     "seir_sampler_time_grad_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.POINTER(ctypes.c_float)]),
+    "seir_sampler_pair_timeouts": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
 }
 
 _lib = None
@@ -141,6 +149,8 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
+        if lib.seir_abi_version() != ABI_VERSION:
+            raise SeirError(f"{LIB_PATH} has ABI {lib.seir_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
         _lib = lib
     return _lib
 

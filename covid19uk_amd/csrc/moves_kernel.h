@@ -130,7 +130,8 @@ __device__ inline void mv_draw(const SamplerCfg &s, const Chains &ch, int b, Mov
     // one lane per draw slot (slot 15 = the accept uniform), broadcast through LDS
     if (tid < 2 * MMAX) rng_uniform2(key, stream, (uint32_t)tid, sm.u[tid][0], sm.u[tid][1]);
     if (tid == 64) {
-        mv.valid = 1; mv.n = 0; mv.tgt = spec.tgt; mv.kind = spec.kind; mv.slot = spec.slot;
+        mv.valid = (s.disable_mask >> (1 + spec.slot)) & 1 ? 0 : 1;    // disabled sub-kernel: drawn, never accepted
+        mv.n = 0; mv.tgt = spec.tgt; mv.kind = spec.kind; mv.slot = spec.slot;
         mv.logq = 0.0; mv.any_dI = 0; mv.LO = T; mv.HI = -1;
         for (int j = 0; j < MMAX; ++j) { mv.tm[j] = mv.tt[j] = mv.tdt[j] = mv.tx[j] = 0; mv.b[j] = -1; sm.pend_valid[j] = -1; }
         double ua, ub;
@@ -820,8 +821,12 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     __shared__ double2 ltab[LDSTAB_N];
     __shared__ int s_sel, s_acc_se, s_conf, s_late;
     debug_skew(d);
-    const int role = blockIdx.x / nbk;
-    const int b = d.b0 + (int)blockIdx.x - role * nbk, tid = threadIdx.x;
+    // block id = (1 - role) * nbk + chain: the speculative workgroups (role 1) have the lower ids and are
+    // dispatched first, so an authoritative workgroup never holds a CU waiting for a partner that has
+    // not been placed yet, whatever the number of chains; the closing launch has role 0 only
+    const int half = (int)blockIdx.x / nbk;
+    const int role = gridDim.x > (unsigned)nbk ? 1 - half : 0;
+    const int b = d.b0 + (int)blockIdx.x - half * nbk, tid = threadIdx.x;
     const int M = d.M, T = d.T;
     const bool do_se = role == 0 && se.kind >= 0, do_nx = next.kind >= 0;
     if (role == 1 && !do_nx) return;
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         // test hooks (SEIR_DEBUG_PAIR): 1 = post the token late, 2 = never post it
         if (dbg & 1)
             for (int i = 0; i < 400; ++i) __builtin_amdgcn_s_sleep(127);
-        if (tid == 0 && !(dbg & 2)) __hip_atomic_store(ch.hand + b, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !(dbg & 2)) __hip_atomic_store(ch.hand + b, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
     unsigned tr_slot = 0xffffffffu;
@@ -899,6 +904,9 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
                 ++spins;
             }
             s_late = spins >= 4000 ? 1 : 0;
+            if (spins >= 4000) ch.late[b] += 1;                // visible through seir_sampler_pair_timeouts
+            // relaxed polls, one acquire once the token is seen: this workgroup's stores below are ordered after it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         lds_barrier();
         late = s_late != 0;

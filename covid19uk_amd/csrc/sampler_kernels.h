@@ -46,7 +46,8 @@ struct SamplerCfg {
     int adapt_step, adapt_mass, n_adapt;
     double target_accept;
     int cap;          // trace slots
-    int nrb_d;        // row blocks of k_move_delta / k_move_pa
+    int nrb_d;        // row blocks of k_move_delta / k_move_pa2
+    int disable_mask; // bit 0 HMC, bits 1..4 the four event sub-kernels: proposal drawn, always rejected
 };
 
 struct Move {
@@ -71,6 +72,7 @@ struct Chains {
     Move *fpend;                                         // [B] accepted E->I-type update whose F band is still to be applied (valid = 1)
     Move *mvfix;                                         // [2][B] E->I-type proposal re-drawn after a row conflict (k_move_pair)
     unsigned *hand;                                      // [B] k_move_pair: token of the launch whose role 1 has its totals
+    unsigned *late;                                      // [B] k_move_pair: launches whose role 0 gave up waiting for role 1
     int *mvsel;                                          // [2][B] 1: the pending descriptor is mvfix, 0: mv[buf]
     double *Dpart;                                       // [B][nrb_d][2]
     double *Down;                                        // [2][2][B][2] paired form: own-rows log-ratio of the speculative /
@@ -469,19 +471,13 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
             rng_uniform2(key, RS_HMC_ACCEPT, 0u, u1, u2);
             const double lp0 = hs[HS_LP0];
             const double log_ratio = (lp_theta - lp0) - (kin - hs[HS_K0]);
-            const int acc = cold_log(u1) < log_ratio ? 1 : 0;     // NaN compares false -> reject
+            const int acc = (cold_log(u1) < log_ratio && !(s.disable_mask & 1)) ? 1 : 0;   // NaN compares false -> reject
             s_accept = acc;
             hs[HS_ACC] = (double)acc;
             hs[HS_LOGACC] = log_ratio;
             const double lpt = acc ? lp_theta : lp0;
             hs[HS_LP_THETA] = lpt;
-            const unsigned slot = ch.sweep[b] - ch.slot0[0];
-            if (slot < (unsigned)s.cap) {
-                double *tr = ch.tr_hmc + ((size_t)slot * s.B + b) * 3;
-                tr[0] = (double)acc;
-                tr[1] = lpt + hs[HS_LP_CONST];
-                tr[2] = eps;
-            }
+            double eps_traced = eps;
             if (s.adapt_step) {                       // dual averaging (Hoffman & Gelman alg. 5, TFP defaults)
                 const double a = isfinite(log_ratio) ? fmin(1.0, cold_exp(log_ratio)) : 0.0;
                 const double prev_step = hs[HS_DA_STEP];
@@ -491,8 +487,20 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
                 const double eta = cold_exp(-0.75 * cold_log(n));
                 const double log_avg = eta * log_step + (1.0 - eta) * hs[HS_DA_LOGAVG];
                 hs[HS_DA_ERR] = err; hs[HS_DA_STEP] = n; hs[HS_DA_LOGAVG] = log_avg;
-                if (prev_step <= (double)s.n_adapt)
-                    hs[HS_EPS] = cold_exp(prev_step < (double)s.n_adapt ? log_step : log_avg);
+                if (prev_step <= (double)s.n_adapt) {
+                    eps_traced = cold_exp(prev_step < (double)s.n_adapt ? log_step : log_avg);
+                    hs[HS_EPS] = eps_traced;
+                }
+            }
+            // trace_results_fn reads step_size from the kernel results AFTER DualAveragingStepSizeAdaptation
+            // has written new_step_size back (inference.py:255-261): the traced value is the step size the
+            // NEXT sweep will use, which is what run_mcmc averages over the last 25 draws (inference.py:439-441)
+            const unsigned slot = ch.sweep[b] - ch.slot0[0];
+            if (slot < (unsigned)s.cap) {
+                double *tr = ch.tr_hmc + ((size_t)slot * s.B + b) * 3;
+                tr[0] = (double)acc;
+                tr[1] = lpt + hs[HS_LP_CONST];
+                tr[2] = eps_traced;
             }
         }
         __syncthreads();
@@ -980,217 +988,7 @@ __device__ inline int comp_start(const Dims &d, const Work &w, size_t rowoff, in
     return v;
 }
 
-// block-wide helpers over a 256-thread workgroup -----------------------------
-__device__ inline int block_sum_int(int v, int *sh) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-__device__ inline int block_min_int(int v, int *sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, WAVE));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return min(min(sh[0], sh[1]), min(sh[2], sh[3]));
-}
-
-// Index of the r-th (0-based) element with flag set among n elements, where
-// element i's flag is flag(i).  Each thread owns a contiguous segment; the
-// prefix counts come from wave shuffles (3 barriers in all).
-// Returns -1 if r >= count.  `count_out` receives the number of set flags.
-template <typename FlagFn>
-__device__ inline int block_select(int n, int r, FlagFn flag, int *cnt_sh /*[>=4]*/, int *res_sh, int &count_out) {
-    const int tid = threadIdx.x;
-    const int per = (n + 255) / 256;
-    const int lo = tid * per, hi = min(n, lo + per);
-    int c = 0;
-    for (int i = lo; i < hi; ++i) c += flag(i) ? 1 : 0;
-    int total;
-    const int before = block_excl_scan_256(c, cnt_sh, total);
-    count_out = total;
-    if (tid == 0) *res_sh = -1;
-    __syncthreads();
-    if (r >= before && r < before + c) {
-        int k = r - before;
-        for (int i = lo; i < hi; ++i)
-            if (flag(i)) {
-                if (k == 0) { *res_sh = i; break; }
-                --k;
-            }
-    }
-    __syncthreads();
-    return *res_sh;
-}
-
-// min over tau in (lo, hi] of comp_start(comp, tau); INT_MAX for an empty range
-__device__ inline int block_range_min(const Dims &d, const Work &w, size_t rowoff, int comp, int lo, int hi, int *sh) {
-    int v = 0x7fffffff;
-    for (int tau = lo + 1 + (int)threadIdx.x; tau <= hi; tau += 256) v = min(v, comp_start(d, w, rowoff, comp, tau));
-    return block_min_int(v, sh);
-}
-
 struct MoveSpec { int kind, tgt, slot, scan; };   // slot 0..3 = S->E move, E->I move, S->E occult, E->I occult
-
-// Proposal for one chain by one workgroup; writes ch.mv[b].
-__device__ inline void propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
-                               MoveSpec spec, int nbuf, int *cnt_sh, int *ish) {
-    __shared__ Move mv;
-    __shared__ int res_sh;
-    const int tid = threadIdx.x;
-    const RngKey key = rng_key(s, ch, b);
-    const uint32_t stream = RS_MOVE_BASE + (uint32_t)(spec.scan * 4 + spec.slot);
-    const int tgt = spec.tgt;
-    const int *rowtot = w.rowtot + ((size_t)b * 2 + tgt) * d.Mp;
-    if (tid == 0) {
-        mv.valid = 1; mv.n = 0; mv.tgt = tgt; mv.kind = spec.kind; mv.slot = spec.slot;
-        mv.logq = 0.0; mv.any_dI = 0; mv.LO = d.T; mv.HI = -1;
-        for (int j = 0; j < MMAX; ++j) { mv.tm[j] = mv.tt[j] = mv.tdt[j] = mv.tx[j] = 0; mv.b[j] = -1; }
-        double ua, ub;
-        rng_uniform2(key, stream, 15u, ua, ub);
-        mv.logu = log(ua);
-    }
-    __syncthreads();
-
-    if (spec.kind == 0) {
-        // ---- UncalibratedEventTimesUpdate ---------------------------------
-        int H;
-        (void)block_select(d.M, 0x7fffffff, [&](int m) { return rowtot[m] > 0; }, cnt_sh, &res_sh, H);
-        const int nsel = min(min(s.mmax, MMAX), H);
-        int chosen_pos[MMAX];
-        for (int j = 0; j < nsel; ++j) {
-            double u_m, u_t, u_d, u_x;
-            rng_uniform2(key, stream, (uint32_t)(2 * j), u_m, u_t);
-            rng_uniform2(key, stream, (uint32_t)(2 * j + 1), u_d, u_x);
-            // j-th distinct hot row: position among the remaining hot rows
-            int pos = rng_index(u_m, H - j);
-            for (int a = 0; a < j; ++a) {            // chosen_pos kept ascending
-                if (pos >= chosen_pos[a]) ++pos;
-            }
-            int ins = j;
-            while (ins > 0 && chosen_pos[ins - 1] > pos) { chosen_pos[ins] = chosen_pos[ins - 1]; --ins; }
-            chosen_pos[ins] = pos;
-            int dummy;
-            const int m = block_select(d.M, pos, [&](int mm) { return rowtot[mm] > 0; }, cnt_sh, &res_sh, dummy);
-            const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
-            const int *krow = w.K[tgt] + rowoff;
-            int D;
-            (void)block_select(d.T, 0x7fffffff, [&](int t) { return krow[t] > 0; }, cnt_sh, &res_sh, D);
-            const int t = block_select(d.T, rng_index(u_t, D), [&](int tt) { return krow[tt] > 0; }, cnt_sh, &res_sh,
-                                       dummy);
-            const int v = rng_index(u_d, 2 * s.dmax);
-            const int delta = v < s.dmax ? v - s.dmax : v - s.dmax + 1;
-            const int t2 = t + delta;
-            if (t2 < 0 || t2 >= d.T) {               // out of range: auto-reject (target_log_prob = -inf)
-                if (tid == 0) {
-                    mv.valid = 0;
-                    mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = 0;
-                }
-                __syncthreads();
-                continue;
-            }
-            const int lo = min(t, t2), hi = max(t, t2);
-            const int src = tgt, dst = tgt + 1;
-            // the compartment that LOSES x on (lo,hi]: dest if moved later, source if moved earlier
-            const int dec = delta > 0 ? dst : src, inc = delta > 0 ? src : dst;
-            const bool dec_unbounded = (dec == 0);   // S: prev_event_id None -> no bound
-            const bool inc_unbounded = (inc == 0);
-            const int min_dec = dec_unbounded ? 0x7fffffff : block_range_min(d, w, rowoff, dec, lo, hi, ish);
-            const int min_inc = inc_unbounded ? 0x7fffffff : block_range_min(d, w, rowoff, inc, lo, hi, ish);
-            if (tid == 0) {
-                const int kt = krow[t], kt2 = krow[t2];
-                const int xmax = max(0, min(min(s.nmax, kt), min_dec));
-                const int x = rng_index(u_x, xmax + 1);
-                // reverse move from t2 back to t on the proposed events
-                const int Dn = D - ((x > 0 && x == kt) ? 1 : 0) + ((x > 0 && kt2 == 0) ? 1 : 0);
-                const long long binc = inc_unbounded ? 0x7fffffffLL : (long long)min_inc + x;
-                const int xmax_r = (int)max(0LL, min((long long)min(s.nmax, kt2 + x), binc));
-                mv.logq += (-log((double)Dn) - log((double)(xmax_r + 1))) - (-log((double)D) - log((double)(xmax + 1)));
-                const int i = mv.n++;
-                mv.m[i] = m; mv.a[i] = t; mv.b[i] = t2; mv.dka[i] = -x; mv.dkb[i] = x;
-                mv.lo[i] = lo; mv.hi[i] = hi;
-                mv.dsrc[i] = delta > 0 ? x : -x;     // moved later: source keeps x longer
-                mv.LO = min(mv.LO, lo); mv.HI = max(mv.HI, hi);
-                if (tgt == 1 && x != 0) mv.any_dI = 1;
-                mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = x;
-            }
-            __syncthreads();
-        }
-    } else {
-        // ---- UncalibratedOccultUpdate --------------------------------------
-        const int R = s.tr_hi - s.tr_lo;
-        double u_br, u_m, u_t, u_x;
-        rng_uniform2(key, stream, 0u, u_br, u_m);
-        rng_uniform2(key, stream, 1u, u_t, u_x);
-        auto range_tot = [&](int m) {
-            const int *kr = w.K[tgt] + ((size_t)b * d.Mp + m) * d.Tp;
-            int sum = 0;
-            for (int t = s.tr_lo; t < s.tr_hi; ++t) sum += kr[t];
-            return sum;
-        };
-        int Hd;
-        (void)block_select(d.M, 0x7fffffff, [&](int m) { return range_tot(m) > 0; }, cnt_sh, &res_sh, Hd);
-        const bool is_del = (u_br < 0.5) && Hd > 0;
-        const int src = tgt, dst = tgt + 1;
-        int m, t, dummy;
-        if (!is_del) {
-            m = rng_index(u_m, d.M);
-            t = s.tr_lo + rng_index(u_t, R);
-        } else {
-            m = block_select(d.M, rng_index(u_m, Hd), [&](int mm) { return range_tot(mm) > 0; }, cnt_sh, &res_sh, dummy);
-        }
-        const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
-        const int *krow = w.K[tgt] + rowoff;
-        int Dm;                                       // hot days of row m inside the range
-        (void)block_select(R, 0x7fffffff, [&](int i) { return krow[s.tr_lo + i] > 0; }, cnt_sh, &res_sh, Dm);
-        if (is_del)
-            t = s.tr_lo + block_select(R, rng_index(u_t, Dm), [&](int i) { return krow[s.tr_lo + i] > 0; }, cnt_sh,
-                                       &res_sh, dummy);
-        const int rt_m = range_tot(m);
-        const int min_src = src == 0 ? 0x7fffffff : block_range_min(d, w, rowoff, src, t, d.T, ish);
-        const int min_dst = block_range_min(d, w, rowoff, dst, t, d.T, ish);
-        if (tid == 0) {
-            const int kt = krow[t];
-            const double lM = log((double)d.M), lR = log((double)R), l2 = 0.6931471805599453;
-            int x;
-            if (!is_del) {
-                const int xmax = max(0, min(s.occult_nmax, min_src));
-                x = rng_index(u_x, xmax + 1);
-                const double qf = (Hd > 0 ? -l2 : 0.0) - lM - lR - log((double)(xmax + 1));
-                const int Hd2 = Hd + ((rt_m == 0 && x > 0) ? 1 : 0);
-                const int Dm2 = Dm + ((kt == 0 && x > 0) ? 1 : 0);
-                const long long bd = (long long)min_dst + x;
-                const int xmax_r = (int)max(0LL, min((long long)min(s.occult_nmax, kt + x), bd));
-                const double qr = (Hd2 > 0 && kt + x > 0)
-                                      ? -l2 - log((double)Hd2) - log((double)Dm2) - log((double)(xmax_r + 1))
-                                      : -INFINITY;
-                mv.logq = qr - qf;
-                mv.dka[0] = x; mv.dsrc[0] = -x;
-            } else {
-                const int xmax = max(0, min(min(s.occult_nmax, kt), min_dst));
-                x = rng_index(u_x, xmax + 1);
-                const double qf = -l2 - log((double)Hd) - log((double)Dm) - log((double)(xmax + 1));
-                const int Hd2 = Hd - ((x > 0 && rt_m == x) ? 1 : 0);
-                const long long bs = src == 0 ? 0x7fffffffLL : (long long)min_src + x;
-                const int xmax_r = (int)max(0LL, min((long long)s.occult_nmax, bs));
-                const double qr = (Hd2 > 0 ? -l2 : 0.0) - lM - lR - log((double)(xmax_r + 1));
-                mv.logq = qr - qf;
-                mv.dka[0] = -x; mv.dsrc[0] = x;
-            }
-            mv.n = 1;
-            mv.m[0] = m; mv.a[0] = t; mv.b[0] = -1; mv.dkb[0] = 0;
-            mv.lo[0] = t; mv.hi[0] = d.T - 1;
-            mv.LO = t; mv.HI = d.T - 1;
-            mv.any_dI = (tgt == 1 && x != 0) ? 1 : 0;
-            mv.tm[0] = m; mv.tt[0] = t; mv.tdt[0] = is_del ? -1 : 1; mv.tx[0] = x;
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (tid == 0) ch.mv[(size_t)nbuf * s.B + b] = mv;
-}
 
 // Per-cell log-likelihood pieces (the full form the differences below are taken from):
 //   cn = lbinom(S,k_se) + lbinom(E,k_ei) + lbinom(I,k_ir) + k_ei L_ei - (E - k_ei) r_ei       (parameter free)
@@ -1445,93 +1243,6 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
         out[0] = a;
         out[1] = e;
     }
-}
-
-// k_move_pa: (1) finalize the pending proposal -- MetropolisHastings accept
-// test (mcmc_kernel_factory.py:72,99), F column update by every block, row-local
-// state update and trace by block 0 -- then (2) block 0 draws the next proposal.
-// next.kind < 0: finalize only.  grid (nrb_d, B).  The pending descriptor is read from
-// buffer pbuf, the next one written to pbuf^1 (late blocks must not see the new one).
-__global__ __launch_bounds__(256) void k_move_pa(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
-                                                 int have_prev, int pbuf) {
-    __shared__ Move mv;
-    __shared__ int cnt_sh[256];
-    __shared__ int ish[4];
-    __shared__ int s_acc;
-    __shared__ double s_dth, s_dcn, shd[4];
-    const int b = d.b0 + blockIdx.y, tid = threadIdx.x;
-    if (have_prev) {
-        if (tid == 0) mv = ch.mv[(size_t)pbuf * s.B + b];
-        double dth = 0.0, dcn = 0.0;
-        for (int i = tid; i < s.nrb_d; i += 256) {
-            dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
-            dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
-        }
-        dth = block_sum_256(dth, shd);
-        dcn = block_sum_256(dcn, shd);
-        if (tid == 0) {
-            const double ratio = dth + dcn + mv.logq;
-            s_acc = (mv.valid && mv.logu < ratio) ? 1 : 0;   // NaN -> reject
-            s_dth = dth; s_dcn = dcn;
-        }
-        __syncthreads();
-        if (s_acc && mv.any_dI) {
-            // F[j][t] += sum_i Cstar[j][m_i] dI_i / N_{m_i}  on each update's day window
-            const int rows_per_blk = (d.M + s.nrb_d - 1) / s.nrb_d;
-            const int r_lo = blockIdx.x * rows_per_blk, r_hi = min(d.M, r_lo + rows_per_blk);
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int j = r_lo + wave; j < r_hi; j += 4) {
-                double coef[MMAX];
-#pragma unroll
-                for (int i = 0; i < MMAX; ++i)
-                    coef[i] = i < mv.n ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
-                                       : 0.0;
-                double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
-                for (int t = mv.LO + lane; t <= mv.HI; t += WAVE) {
-                    double dF = 0.0;
-#pragma unroll
-                    for (int i = 0; i < MMAX; ++i)
-                        if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
-                    if (dF != 0.0) Fr[t] += dF;
-                }
-            }
-        }
-        if (blockIdx.x == 0) {
-            if (s_acc) {
-                for (int i = 0; i < mv.n; ++i) {
-                    const size_t rowoff = ((size_t)b * d.Mp + mv.m[i]) * d.Tp;
-                    const int src = mv.tgt, dst = mv.tgt + 1;
-                    for (int t = mv.lo[i] + 1 + tid; t <= mv.hi[i]; t += 256) {
-                        w.St[src][rowoff + t] += mv.dsrc[i];
-                        w.St[dst][rowoff + t] -= mv.dsrc[i];
-                        if (mv.tgt == 1) w.Dir[(size_t)b * d.Tp + t] -= (double)mv.dsrc[i];
-                    }
-                    if (tid == 0) {
-                        w.K[mv.tgt][rowoff + mv.a[i]] += mv.dka[i];
-                        if (mv.b[i] >= 0) w.K[mv.tgt][rowoff + mv.b[i]] += mv.dkb[i];
-                        w.rowtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += mv.dka[i] + mv.dkb[i];
-                    }
-                    __syncthreads();     // two updates may touch the same Dir[t]
-                }
-            }
-            if (tid == 0) {
-                double *hs = ch.hs + (size_t)b * NHS;
-                if (s_acc) { hs[HS_LP_THETA] += s_dth; hs[HS_LP_CONST] += s_dcn; }
-                const unsigned slot = ch.sweep[b] - ch.slot0[0];
-                if (slot < (unsigned)s.cap) {
-                    double *tr = ch.tr_mv + (((size_t)slot * s.B + b) * 4 + mv.slot) * NMVTR;
-                    tr[0] = (double)s_acc;
-                    tr[1] = hs[HS_LP_THETA] + hs[HS_LP_CONST];
-                    for (int j = 0; j < MMAX; ++j) {
-                        tr[2 + j] = mv.tm[j]; tr[2 + MMAX + j] = mv.tt[j];
-                        tr[2 + 2 * MMAX + j] = mv.tdt[j]; tr[2 + 3 * MMAX + j] = mv.tx[j];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (blockIdx.x == 0 && next.kind >= 0) propose(d, w, s, ch, b, next, pbuf ^ 1, cnt_sh, ish);
 }
 
 // End of sweep: record the event tensor in the reference's [M][T][3] order.  One wave per row,

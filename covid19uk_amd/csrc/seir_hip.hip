@@ -52,6 +52,7 @@ struct seir_ctx {
     const double *last_u = nullptr, *last_events = nullptr;
     double *last_logp = nullptr, *last_grad = nullptr;
     bool prepared = false;
+    int opt_skew = 0, opt_affinity = 3;     // seir_set_option
 };
 
 static inline int ceil_to(int x, int q) { return (x + q - 1) / q * q; }
@@ -265,16 +266,27 @@ static int check_batch(seir_ctx *ctx, int B) {
 // `d.b0` selects the first chain, `nb` the number of chains, `st` the stream.
 // `affinity`: give every block of a chain the same (block id % 8), see xcd_affine()
 struct LaunchCfg { Dims d; hipStream_t st; int nb; int affinity; };
-// SEIR_XCD_AFFINITY: bit 0 = gradient kernel, bit 1 = event-move kernels (default 3)
-static int affinity_enabled() {
-    const char *e = getenv("SEIR_XCD_AFFINITY");     // read per call: launches are enqueued at graph capture
-    return e ? atoi(e) : 3;
-}
+// affinity: bit 0 = gradient kernel, bit 1 = event-move kernels (seir_set_option, default 3)
 static LaunchCfg whole(seir_ctx *ctx, int B) {
-    LaunchCfg l{ctx->d, ctx->stream, B, affinity_enabled()};
-    const char *e = getenv("SEIR_DEBUG_SKEW");          // test hook, see debug_skew()
-    l.d.skew = e ? atoi(e) : 0;
+    LaunchCfg l{ctx->d, ctx->stream, B, ctx->opt_affinity};
+    l.d.skew = ctx->opt_skew;                           // test hook, see debug_skew()
     return l;
+}
+
+extern "C" int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value) {
+    if (!ctx) return fail(SEIR_ERR_INVALID, "null context");
+    switch (option) {
+        case SEIR_OPT_DEBUG_SKEW:
+            if (value < 0 || value > 3) return fail(SEIR_ERR_INVALID, "debug skew must be 0..3");
+            ctx->opt_skew = value;
+            return 0;
+        case SEIR_OPT_XCD_AFFINITY:
+            if (value < 0 || value > 3) return fail(SEIR_ERR_INVALID, "xcd affinity is a 2-bit mask");
+            ctx->opt_affinity = value;
+            return 0;
+        default:
+            return fail(SEIR_ERR_INVALID, "unknown option %d", option);
+    }
 }
 
 template <int SRC>
@@ -669,11 +681,11 @@ struct seir_sampler {
     std::vector<hipGraphExec_t> gexec;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
-    bool use_graph = true;
-    bool legacy_moves = false;    // SEIR_MOVES=legacy: first implementation of the proposal kernel (k_move_pa)
-    bool hmc_chunked = true;      // SEIR_HMC=single: every leapfrog step by the single-workgroup kernel
-    int pair_debug = 0;           // SEIR_DEBUG_PAIR: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
-    int moves_mode = 0;           // 0 = paired launches (k_move_pair); 1 = one proposal kernel per update (split / legacy)
+    bool use_graph = false;       // seir_sampler_desc::use_graph
+    bool hmc_chunked = true;      // hmc_mode 1: every leapfrog step by the single-workgroup kernel
+    int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
+    int moves_mode = 0;           // 0 = paired launches (k_move_pair); 1 = one proposal kernel per update (k_move_pa2)
+    int graph_skew = 0, graph_aff = 3;   // context options the captured graph was built with
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
 };
@@ -726,6 +738,9 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         return fail(SEIR_ERR_INVALID, "occult t_range [%d,%d) outside [0,%d)", ds->t_range_lo, ds->t_range_hi, d.T);
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
+    if (ds->moves_mode < 0 || ds->moves_mode > 1 || ds->hmc_mode < 0 || ds->hmc_mode > 1)
+        return fail(SEIR_ERR_INVALID, "moves_mode and hmc_mode are 0 or 1");
+    if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
     if (!s) return fail(SEIR_ERR_DEVICE, "out of host memory");
@@ -744,23 +759,13 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     // stream launches 0.815 ms per sweep, replay of the captured hipGraph 0.872 ms -- the graph
     // executor costs ~0.75 us more per node than the stream path while the host (3-4 us per launch,
     // kernels of ~10 us) stays ahead either way.  Default: stream launches; SEIR_GRAPH=1 selects the graph.
+    s->use_graph = ds->use_graph != 0;
+    s->pair_debug = ds->debug_pair;
+    s->hmc_chunked = ds->hmc_mode == 0;
+    s->moves_mode = ds->moves_mode;
+    c.disable_mask = ds->disable_mask;
     {
-        const char *e = getenv("SEIR_GRAPH");
-        s->use_graph = e && atoi(e) != 0 && getenv("SEIR_NO_GRAPH") == nullptr;
-    }
-    {
-        const char *dbgp = getenv("SEIR_DEBUG_PAIR");
-        s->pair_debug = dbgp ? atoi(dbgp) : 0;
-        const char *h = getenv("SEIR_HMC");
-        s->hmc_chunked = !(h && strcmp(h, "single") == 0);
-        // SEIR_MOVES: (default) paired launches | "split": k_move_pa2 per update | "legacy": k_move_pa per update
-        const char *e = getenv("SEIR_MOVES");
-        s->legacy_moves = e && strcmp(e, "legacy") == 0;
-        s->moves_mode = (e && (strcmp(e, "legacy") == 0 || strcmp(e, "split") == 0)) ? 1 : 0;
-    }
-    {
-        const char *e = getenv("SEIR_CHAIN_GROUPS");
-        int g = e ? atoi(e) : 1;     // measured: concurrent graphs on several streams do not overlap profitably
+        int g = ds->chain_groups;    // measured: concurrent chain groups on several streams do not overlap profitably
         if (g < 1) g = 1;
         if (g > B) g = B;
         s->ngroups = g;
@@ -791,6 +796,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.mvfix, (size_t)2 * B);
     S_ALLOC(ch.mvsel, (size_t)2 * B);
     S_ALLOC(ch.hand, (size_t)B);
+    S_ALLOC(ch.late, (size_t)B);
     S_ALLOC(ch.Dpart, (size_t)B * c.nrb_d * 2);
     S_ALLOC(ch.Down, (size_t)2 * 2 * B * 2);
     S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
@@ -1030,12 +1036,9 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     const SamplerCfg &c = s->cfg;
     int b0, nb;
     group_range(s, g, b0, nb);
-    LaunchCfg l{ctx->d, s->gstream[g], nb, affinity_enabled()};
+    LaunchCfg l{ctx->d, s->gstream[g], nb, ctx->opt_affinity};
     l.d.b0 = b0;
-    {
-        const char *e = getenv("SEIR_DEBUG_SKEW");
-        l.d.skew = e ? atoi(e) : 0;
-    }
+    l.d.skew = ctx->opt_skew;
     const Dims d0 = l.d;
     hipStream_t st = l.st;
     // [part 0] HMC on u | events: L+1 gradient evaluations
@@ -1084,8 +1087,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     Dims d = l.d;
     int advanced = 0;
     {
-        // the legacy proposal kernel keeps the natural (row block, chain) grid
-        const bool aff = (l.affinity & 2) && !s->legacy_moves && xcd_affinity_applies(c.nrb_d, nb);
+        const bool aff = (l.affinity & 2) && xcd_affinity_applies(c.nrb_d, nb);
         d.aff_nb = aff ? nb : 0;
         const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
@@ -1114,26 +1116,17 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             for (int scan = 0; scan < c.n_scans; ++scan)
                 for (int slot = 0; slot < 4; ++slot) {
                     const MoveSpec spec{slot >= 2 ? 1 : 0, slot & 1, slot, scan};
-                    if (s->legacy_moves)
-                        hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, spec, have_prev,
-                                           pbuf);
-                    else
-                        hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
-                                           have_prev, pbuf);
+                    hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
+                                       have_prev, pbuf);
                     pbuf ^= 1;
                     hipLaunchKernelGGL((k_move_delta<true>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 0);
                     have_prev = 1;
                 }
             if (have_prev) {
-                // closing launch: finalize the last proposal; k_move_pa2 also advances the sweep counter
-                if (s->legacy_moves) {
-                    const MoveSpec none{-1, 0, 0, 0};
-                    hipLaunchKernelGGL(k_move_pa, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
-                } else {
-                    const MoveSpec none{-2, 0, 0, 0};
-                    hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
-                    advanced = 1;
-                }
+                // closing launch: finalize the last proposal and advance the sweep counter
+                const MoveSpec none{-2, 0, 0, 0};
+                hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+                advanced = 1;
             }
         }
     }
@@ -1154,6 +1147,10 @@ extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
     for (int g = 0; g < s->ngroups; ++g) {
         hipStream_t st = s->gstream[g];
         HIP_TRY(hipStreamWaitEvent(st, s->ev_fork, 0));
+        if (s->use_graph && (s->graph_skew != s->ctx->opt_skew || s->graph_aff != s->ctx->opt_affinity)) {
+            drop_graph(s);                           // launch options are baked into the captured kernels
+            s->graph_skew = s->ctx->opt_skew; s->graph_aff = s->ctx->opt_affinity;
+        }
         if (s->use_graph && !s->gexec[g]) {
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             enqueue_sweep(s, g);
@@ -1219,6 +1216,15 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     HIP_TRY(hipGetLastError());
     *mean_ms = ms / iters;
+    return 0;
+}
+
+extern "C" int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (!out) return fail(SEIR_ERR_INVALID, "null pointer");
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    HIP_TRY(hipMemcpy(out, s->ch.late, sizeof(uint32_t) * s->cfg.B, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -291,6 +291,35 @@ class File:
         _check(rc, f"read {name!r}")
         return out
 
+    def read_rows(self, name, start, count, stride=1):
+        """ds[start : start + count*stride : stride] read as ONE strided hyperslab along axis 0 (what h5py
+        does for `ds[a:b:c]`): only the selected rows leave the file.  Numeric datasets only."""
+        lib = self._lib
+        d = self._open(name)
+        shape = self.shape(name)
+        start, count, stride = int(start), int(count), int(stride)
+        if not shape or stride < 1 or start < 0 or count < 0 or (count and start + (count - 1) * stride >= shape[0]):
+            raise ValueError(f"read_rows({name!r}): rows {start}:+{count}:{stride} outside {shape}")
+        ftype = lib.H5Dget_type(d)
+        cls = lib.H5Tget_class(ftype)
+        lib.H5Tclose(ftype)
+        if cls == H5T_STRING:
+            raise ValueError(f"read_rows({name!r}): string datasets are read whole")
+        out = np.empty((count,) + shape[1:], dtype=np.float64 if cls == H5T_FLOAT else np.int64)
+        if count == 0:
+            return out
+        nd = len(shape)
+        fspace = lib.H5Dget_space(d)
+        _check(lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, _dims((start,) + (0,) * (nd - 1)),
+                                       _dims((stride,) + (1,) * (nd - 1)), _dims((count,) + shape[1:]), None),
+               f"select rows of {name!r}")
+        mspace = lib.H5Screate_simple(nd, _dims(out.shape), None)
+        rc = lib.H5Dread(d, _ids[_NATIVE[out.dtype]], mspace, fspace, H5P_DEFAULT, out.ctypes.data_as(ctypes.c_void_p))
+        lib.H5Sclose(mspace)
+        lib.H5Sclose(fspace)
+        _check(rc, f"read rows of {name!r}")
+        return out
+
     def read_str_attr(self, obj, attr):
         """String attribute `attr` of object `obj`, or None."""
         lib = self._lib

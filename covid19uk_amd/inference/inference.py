@@ -158,7 +158,7 @@ def get_weighted_running_variance(u_draws):
     """inference.py:36-47: mean/variance of the second half of a window's (unconstrained)
     draws, with pseudo-count n/2.  u_draws [n,B,P] -> (count [B], mean [B,P], var [B,P])."""
     n = u_draws.shape[0]
-    half = u_draws[-(n // 2):]
+    half = u_draws[(-n) // 2:]      # as the reference's `draws[-draws.shape[0] // 2:]`: floor of the NEGATIVE -> 13 of 25
     mean, var = half.mean(axis=0), half.var(axis=0)
     return np.full(u_draws.shape[1], n / 2.0), mean, np.maximum(var, 1e-300)
 
@@ -224,7 +224,7 @@ def run_mcmc(sampler: ChainSampler, config, posteriors, log=sys.stderr):
     tr, _ = window(last_window_size, False)
 
     print("Sampling...", file=log, flush=True)
-    step_size = tr.hmc["step_size"][-(last_window_size // 2):].mean(axis=0)      # inference.py:439-441
+    step_size = tr.hmc["step_size"][(-last_window_size) // 2:].mean(axis=0)      # inference.py:439-441
     sampler.set_adaptation(adapt_step_size=False)
     sampler.set_kernel(step_size=step_size, variance=sampler.get_kernel()[1])
     nb, ns = int(config["num_bursts"]), int(config["num_burst_samples"])

@@ -33,9 +33,21 @@ class Trace:
 class ChainSampler:
     def __init__(self, model: SeirModel, config: dict, num_chains: int, seed: int = 0,
                  t_range=None, num_leapfrog_steps: int = 16, trace_capacity: int = 100,
-                 first_chain_id: int = 0, record_events: bool = True):
+                 first_chain_id: int = 0, record_events: bool = True, moves: str = "paired",
+                 hmc: str = "chunk", use_graph: bool = False, chain_groups: int = 1,
+                 disable: tuple = (), debug_pair: int = 0):
         """`config` is the reference's config["Mcmc"] dict: dmax, nmax, m,
-        occult_nmax, num_event_time_updates (mcmc_kernel_factory.py:79-81,106,123)."""
+        occult_nmax, num_event_time_updates (mcmc_kernel_factory.py:79-81,106,123).
+
+        Launch form (seir_sampler_desc, ABI v2; none of it changes what is sampled):
+        `moves` "paired" (k_move_pair, default) | "split" (one proposal kernel per update, cross-check);
+        `hmc` "chunk" (default) | "single"; `use_graph`; `chain_groups`.
+        `disable`: sub-kernels that draw their proposal but always reject, any of
+        "hmc", "move/S->E", "move/E->I", "occult/S->E", "occult/E->I" (invariant-distribution tests)."""
+        names = ("hmc",) + MOVE_KEYS
+        mask = 0
+        for name in disable:
+            mask |= 1 << names.index(name)
         self._lib = _lib.load()
         self.model = model
         self.B = int(num_chains)
@@ -52,7 +64,10 @@ class ChainSampler:
             t_range_lo=int(t_range[0]), t_range_hi=int(t_range[1]),
             num_leapfrog_steps=int(num_leapfrog_steps), trace_capacity=self.cap,
             first_chain_id=int(first_chain_id), record_events=int(self.record_events),
-            seed=int(seed) & (2 ** 64 - 1))
+            seed=int(seed) & (2 ** 64 - 1),
+            moves_mode={"paired": 0, "split": 1}[moves], hmc_mode={"chunk": 0, "single": 1}[hmc],
+            use_graph=int(bool(use_graph)), chain_groups=int(chain_groups), disable_mask=mask,
+            debug_pair=int(debug_pair))
         self._s = ctypes.c_void_p()
         _lib.check(self._lib.seir_sampler_create(model._ctx, ctypes.byref(desc), ctypes.byref(self._s)))
 
@@ -154,6 +169,12 @@ class ChainSampler:
         self.reset_trace()
         self.run(num_sweeps)
         return self.read_trace(num_sweeps, events=events)
+
+    def pair_timeouts(self) -> np.ndarray:
+        """Per chain: k_move_pair launches whose authoritative workgroup gave up on the speculative one."""
+        out = np.zeros(self.B, dtype=np.uint32)
+        _lib.check(self._lib.seir_sampler_pair_timeouts(self._s, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        return out
 
     def time_grad_kernel(self, iters: int = 100) -> float:
         """Mean duration (ms) of the sweep's gradient kernel, HIP events on the context stream."""

@@ -129,6 +129,14 @@ class SeirModel:
     def sync(self):
         _lib.check(self._lib.seir_sync(self._ctx))
 
+    def set_option(self, debug_skew=None, xcd_affinity=None):
+        """Launch options of the context (seir_set_option): the workgroup-timing test hook and the
+        chain <-> XCD block mapping.  Neither changes a result."""
+        if debug_skew is not None:
+            _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_DEBUG_SKEW, int(debug_skew)))
+        if xcd_affinity is not None:
+            _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_XCD_AFFINITY, int(xcd_affinity)))
+
     # -- timing (HIP events on the context stream) ----------------------------
     def timer_start(self):
         _lib.check(self._lib.seir_timer_start(self._ctx))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SEIR_ABI_VERSION 1
+#define SEIR_ABI_VERSION 2
 
 typedef enum {
     SEIR_OK = 0,
@@ -101,6 +101,15 @@ int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_dev,
 int seir_sync(seir_ctx *ctx);
 void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context */
 
+/* Launch options of a context (no reference counterpart; nothing here changes a result):
+ *   SEIR_OPT_DEBUG_SKEW      0 off; 1..3: test hook, a pseudo-random third of the workgroups of every
+ *                            launch starts ~30 us late (results must not depend on workgroup timing)
+ *   SEIR_OPT_XCD_AFFINITY    bit 0 gradient kernel, bit 1 event-update kernels: chain <-> XCD affine block
+ *                            mapping (default 3); speed only
+ * Options are read when a launch is enqueued (for a sampler using graph replay: at capture). */
+enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1 };
+int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value);
+
 /* Device memory helpers so that a ctypes host can keep inputs resident
  * without torch (torch tensors' data_ptr() work just as well). */
 int seir_malloc(void **dev_ptr, uint64_t bytes);
@@ -159,6 +168,19 @@ typedef struct {
     int32_t first_chain_id;         /* global id of chain 0: selects the RNG stream (multi-GPU sharding) */
     int32_t record_events;          /* 1: record samples/seir for every draw */
     uint64_t seed;
+    /* ---- ABI v2: launch form and test hooks; all-zero = the defaults ---------------------------- */
+    int32_t moves_mode;             /* 0: paired event-update launches (k_move_pair); 1: one proposal kernel
+                                       per update (k_move_pa2) -- kept as a cross-check, same draws */
+    int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks (k_hmc_chunk); 1: every step
+                                       by the single-workgroup kernel -- same draws up to summation order */
+    int32_t use_graph;              /* 1: replay the sweep as a captured hipGraph (default: stream launches) */
+    int32_t chain_groups;           /* chains split over this many streams (0 or 1: one stream) */
+    int32_t disable_mask;           /* bit 0: HMC update, bits 1..4: S->E move, E->I move, S->E occult, E->I
+                                       occult.  A disabled sub-kernel still draws its proposal (the random
+                                       streams do not shift) but is always rejected -- used by the
+                                       invariant-distribution tests to run each MH kernel alone */
+    int32_t debug_pair;             /* test hooks of k_move_pair's handshake: 1 late, 2 absent speculative role */
+    int32_t reserved[2];
 } seir_sampler_desc;
 
 int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *desc, seir_sampler **out);
@@ -207,6 +229,11 @@ int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, doubl
  * num_leapfrog_steps+1 times per sweep -- replayed `iters` times on the current
  * chain state (it only writes its partial-sum buffers). */
 int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms);
+
+/* Number of k_move_pair launches per chain in which the authoritative workgroup gave up waiting for
+ * the speculative one (it then re-draws the proposal itself: results are unaffected, throughput is
+ * not).  out [B].  Should stay 0 outside the debug_pair test hooks. */
+int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out);
 
 /* ------------------------------------------------------------------------
  * Reproduction number R_it.

@@ -76,13 +76,16 @@ class OracleChain:
     """One chain of the sampler with the device's exact draw protocol."""
 
     def __init__(self, k: so.ModelConstants, config: dict, u, events, seed=0, chain_id=0,
-                 t_range=None, num_leapfrog_steps=16, log_prob_fn=None, log_prob_grad_fn=None):
+                 t_range=None, num_leapfrog_steps=16, log_prob_fn=None, log_prob_grad_fn=None, disable=()):
         """log_prob_fn(u, events) / log_prob_grad_fn(u, events) default to the NumPy oracle;
         the C restatement (oracle/seir_oracle.c) can be passed for large cases."""
         self.k = k
         self._lp_fn = log_prob_fn or (lambda u_, ev_: so.joint_log_prob(u_, ev_, k, "stable"))
         self._lpg_fn = log_prob_grad_fn or (lambda u_, ev_: so.joint_log_prob_and_grad(u_, ev_, k))
         self.cfg = dict(config)
+        # sub-kernels that draw their proposal but always reject (seir_sampler_desc::disable_mask):
+        # any of "hmc", "move/S->E", "move/E->I", "occult/S->E", "occult/E->I"
+        self.disabled = set(disable)
         self.u = np.array(u, dtype=np.float64)
         self.events = np.array(events, dtype=np.float64)
         self.seed, self.chain, self.sweep = int(seed), int(chain_id), 0
@@ -144,7 +147,7 @@ class OracleChain:
         k1 = np.sum(0.5 * var * p * p)
         log_ratio = (lp1 - lp0) - (k1 - k0)
         ua, _ = self._u2(RS_HMC_ACCEPT, 0)
-        acc = bool(math.log(ua) < log_ratio)          # NaN -> False
+        acc = bool(math.log(ua) < log_ratio) and "hmc" not in self.disabled          # NaN -> False
         used_eps = eps
         if acc:
             self.u, self.logp = q, lp1
@@ -169,7 +172,11 @@ class OracleChain:
             self.rv_m2 = self.rv_m2 + dlt * (self.u - self.rv_mean)
             self.rv_n = n1
             self.var = self.rv_m2 / n1
-        return dict(is_accepted=acc, target_log_prob=self.logp, step_size=used_eps, log_accept_ratio=log_ratio)
+        # step_size as the reference traces it: read from the kernel results after
+        # DualAveragingStepSizeAdaptation wrote new_step_size back (inference.py:255-261), i.e. the
+        # step size of the NEXT step; `used_step_size` is the one this trajectory ran with
+        return dict(is_accepted=acc, target_log_prob=self.logp, step_size=self.eps, used_step_size=used_eps,
+                    log_accept_ratio=log_ratio)
 
     # -- event moves ---------------------------------------------------------
     def _closed_state(self):
@@ -233,7 +240,8 @@ class OracleChain:
             new[m, t, tgt] -= x
             new[m, t2, tgt] += x
             tr[:, j] = (m, t, delta, x)
-        acc = self._mh(new, valid, logq, logu)
+        enabled = ("move/S->E", "move/E->I")[tgt] not in self.disabled
+        acc = self._mh(new, valid and enabled, logq, logu)
         return dict(is_accepted=acc, target_log_prob=self.logp, proposed_delta=tr[:, :cfg["m"]],
                     log_q_ratio=logq, valid=valid, proposed_events=new)
 
@@ -288,7 +296,7 @@ class OracleChain:
             xmax_r = max(0, min(nmax, bs))
             qr = (-l2 if Hd2 > 0 else 0.0) - lM - lR - math.log(xmax_r + 1)
             new[m, t, tgt] -= x
-        acc = self._mh(new, True, qr - qf, logu)
+        acc = self._mh(new, ("occult/S->E", "occult/E->I")[tgt] not in self.disabled, qr - qf, logu)
         tr = np.zeros((4, MMAX), dtype=np.int64)
         tr[:, 0] = (m, t, -1 if is_del else 1, x)
         return dict(is_accepted=acc, target_log_prob=self.logp, proposed_delta=tr[:, :cfg["m"]],

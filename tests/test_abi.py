@@ -37,7 +37,15 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.seir_abi_version() == 1
+    text = open(os.path.join(ROOT, "include", "seir_hip.h")).read()
+    declared = int(re.search(r"#define\s+SEIR_ABI_VERSION\s+(\d+)", text).group(1))
+    assert lib.seir_abi_version() == declared == _lib.ABI_VERSION == 2
+
+
+def test_sampler_desc_struct_layout_matches_header():
+    # 12 int32, uint64 seed, then the ABI v2 tail: 6 int32 + 2 reserved
+    assert ctypes.sizeof(_lib.SeirSamplerDesc) == 12 * 4 + 8 + 8 * 4
+    assert _lib.SeirSamplerDesc.seed.offset == 48 and _lib.SeirSamplerDesc.moves_mode.offset == 56
 
 
 def test_desc_struct_layout_matches_header():

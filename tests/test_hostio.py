@@ -109,3 +109,31 @@ def test_thin_posterior_matches_reference_slicing(tmp_path):
     with open(tmp_path / "thin.pkl", "rb") as f:
         again = pickle.load(f)
     assert np.array_equal(again["alpha_t"], theta[idx, 0, 6:6 + T - 1]) and again["initial_state"].shape == (M, 4)
+    # slice() semantics as h5py applies them (thin.py:9): negative and None bounds, ends past the data,
+    # empty selections; and rows read in several bursts (strided hyperslabs, never the whole dataset)
+    from covid19uk_amd.posterior import thin as thin_mod
+    thin_mod.BURST_BYTES = 3 * M * T * 3 * 8
+    for cfg in (dict(start=-7, end=None, by=2), dict(start=None, end=-3, by=4), dict(start=5, end=1000, by=1),
+                dict(start=12, end=3, by=2), dict(start=0, end=20, by=7)):
+        out = thin_posterior(p, str(tmp_path / "thin2.pkl"), cfg)
+        sl = slice(cfg["start"], cfg["end"], cfg["by"])
+        assert np.array_equal(out["seir"], events[sl, 0]), cfg
+        assert np.array_equal(out["spatial_effect"], theta[sl, 0, 6 + T - 1:]), cfg
+
+
+def test_hyperslab_row_reads(tmp_path):
+    from covid19uk_amd import hdf5io
+    p = str(tmp_path / "rows.h5")
+    a = np.arange(11 * 4 * 3, dtype=float).reshape(11, 4, 3)
+    with hdf5io.File(p, "w") as f:
+        f.create_dataset("g/a", a.shape, "float64", chunk_rows=2)
+        f.write("g/a", a)
+        f.create_dataset("v", (11,), "int32")
+        f.write("v", np.arange(11, dtype=np.int32))
+    with hdf5io.File(p, "r") as f:
+        assert np.array_equal(f.read_rows("g/a", 1, 4, 3), a[1:11:3][:4])
+        assert np.array_equal(f.read_rows("g/a", 10, 1), a[10:])
+        assert np.array_equal(f.read_rows("v", 2, 3, 4), np.arange(11)[2::4])
+        assert f.read_rows("g/a", 0, 0).shape == (0, 4, 3)
+        with pytest.raises(ValueError):
+            f.read_rows("g/a", 5, 4, 2)

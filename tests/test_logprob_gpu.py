@@ -204,15 +204,15 @@ def test_device_math_against_mpmath(Model):
         assert abs((mp.mpf(float(iw[i])) - it) / it) < 2e-15, (xw[i], iw[i])
 
 
-def test_evaluation_does_not_depend_on_workgroup_timing(Model, monkeypatch):
-    """SEIR_DEBUG_SKEW starts a third of the workgroups of every launch ~30 us late: the stateless
+def test_evaluation_does_not_depend_on_workgroup_timing(Model):
+    """The debug-skew option starts a third of the workgroups of every launch ~30 us late: the stateless
     evaluation (scan, partial folds, MFMA contraction, S->E tiles) must give the same bits."""
     case = H.build_case("uk380", 15)
     u, ev = _batch(case, 3, 15)
     ref = None
-    for skew in ("0", "1", "2", "3"):
-        monkeypatch.setenv("SEIR_DEBUG_SKEW", skew)
+    for skew in (0, 1, 2, 3):
         with Model(case["cov"], case["init"], max_chains=3) as model:
+            model.set_option(debug_skew=skew)
             got = model.log_prob_grad(u, ev)
         if ref is None:
             ref = got

@@ -55,7 +55,7 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
             assert np.max(np.abs(trace.theta[i, b] - o["theta"]) / scale) < theta_rtol, (i, b, "theta")
 
 
-@pytest.mark.parametrize("moves", ["default", "split", "legacy", "default+single"])
+@pytest.mark.parametrize("moves", ["paired", "split", "paired+single"])
 @pytest.mark.parametrize("name,cfg,seed,eps,n", [
     ("micro_5x24", CFG_SMALL, 1, 0.002, 12),
     ("ni11", CFG_REF, 2, 0.002, 8),
@@ -66,12 +66,11 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
     ("micro_64x64", CFG_SMALL, 6, 0.0001, 3),
     ("micro_65x65", CFG_SMALL, 7, 0.0001, 3),
 ])
-def test_fixed_kernel_sweeps_match_oracle(api, monkeypatch, name, cfg, seed, eps, n, moves):
-    """The three forms of the event-update launches -- paired (k_move_pair, default), one proposal
-    kernel per update (k_move_pa2) and the first implementation (k_move_pa) -- against the oracle."""
+def test_fixed_kernel_sweeps_match_oracle(api, name, cfg, seed, eps, n, moves):
+    """Both forms of the event-update launches -- paired (k_move_pair, default) and one proposal
+    kernel per update (k_move_pa2, the cross-check) -- against the oracle."""
     # "+single": every leapfrog step by the single-workgroup kernel instead of the 64-lane chunks
-    monkeypatch.setenv("SEIR_MOVES", moves.split("+")[0])
-    monkeypatch.setenv("SEIR_HMC", "single" if moves.endswith("+single") else "chunk")
+    form = dict(moves=moves.split("+")[0], hmc="single" if moves.endswith("+single") else "chunk")
     SeirModel, ChainSampler = api
     case = H.build_case(name, seed, alpha_t_sd=0.005)
     B = 2
@@ -82,7 +81,7 @@ def test_fixed_kernel_sweeps_match_oracle(api, monkeypatch, name, cfg, seed, eps
         ch.eps = eps
         oracles.append([ch.sweep_once() for _ in range(n)])
     with SeirModel(case["cov"], case["init"], max_chains=B) as model:
-        with ChainSampler(model, cfg, B, seed=77, first_chain_id=5, trace_capacity=n) as s:
+        with ChainSampler(model, cfg, B, seed=77, first_chain_id=5, trace_capacity=n, **form) as s:
             s.set_state(u, ev)
             lp0 = s.log_prob()
             for b in range(B):
@@ -225,10 +224,10 @@ def test_running_log_prob_matches_full_reevaluation_syn2048(api):
 
 
 @pytest.mark.parametrize("hook", ["1", "2"])
-def test_pair_kernel_handshake_paths(api, monkeypatch, hook):
+def test_pair_kernel_handshake_paths(api, hook):
     """k_move_pair's role 0 waits for role 1's token before its first store (hook 1: the token comes
-    late) and re-draws the E->I proposal itself when role 1 never shows up (hook 2): same traces."""
-    monkeypatch.setenv("SEIR_DEBUG_PAIR", hook)
+    late) and re-draws the E->I proposal itself when role 1 never shows up (hook 2): same traces.
+    The time-outs of hook 2 are counted (seir_sampler_pair_timeouts); an undisturbed run has none."""
     SeirModel, ChainSampler = api
     case = H.build_case("micro_5x24", 1, alpha_t_sd=0.005)
     B, n = 2, 6
@@ -239,11 +238,18 @@ def test_pair_kernel_handshake_paths(api, monkeypatch, hook):
         ch.eps = 0.002
         oracles.append([ch.sweep_once() for _ in range(n)])
     with SeirModel(case["cov"], case["init"], max_chains=B) as model:
-        with ChainSampler(model, CFG_SMALL, B, seed=77, first_chain_id=5, trace_capacity=n) as s:
+        with ChainSampler(model, CFG_SMALL, B, seed=77, first_chain_id=5, trace_capacity=n, debug_pair=int(hook)) as s:
             s.set_state(u, ev)
             s.set_kernel(step_size=0.002)
             tr = s.sample(n)
+            late = s.pair_timeouts()
+        with ChainSampler(model, CFG_SMALL, B, seed=77, first_chain_id=5, trace_capacity=n) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.002)
+            s.sample(n)
+            assert not s.pair_timeouts().any()
     _compare(tr, oracles, n, B, CFG_SMALL)
+    assert (late > 0).all() if hook == "2" else not late.any()
 
 
 @pytest.mark.parametrize("name,B,n,eps", [("uk380", 8, 40, 1.5e-5), ("micro_17x70", 5, 40, 0.0004)])
@@ -274,21 +280,20 @@ def test_repeated_runs_are_bitwise_identical(api, name, B, n, eps):
 
 @pytest.mark.parametrize("forms", ["chunk,paired", "single,split"])
 @pytest.mark.parametrize("name,B,n,eps", [("uk380", 8, 25, 1.5e-5), ("micro_17x70", 5, 25, 0.0004), ("ni11", 2, 25, 0.002)])
-def test_results_do_not_depend_on_workgroup_timing(api, monkeypatch, name, B, n, eps, forms):
-    """SEIR_DEBUG_SKEW delays a pseudo-random third of the workgroups of every launch by ~30 us -- longer
+def test_results_do_not_depend_on_workgroup_timing(api, name, B, n, eps, forms):
+    """The debug-skew option delays a pseudo-random third of the workgroups of every launch by ~30 us -- longer
     than any kernel of the sweep runs -- so a workgroup that reads what another one of the same launch
     writes gets the other version.  All three thirds against the undisturbed run, bit for bit."""
     SeirModel, ChainSampler = api
-    monkeypatch.setenv("SEIR_HMC", forms.split(",")[0])
-    monkeypatch.setenv("SEIR_MOVES", forms.split(",")[1])
+    form = dict(hmc=forms.split(",")[0], moves=forms.split(",")[1])
     case = H.build_case(name, 33, alpha_t_sd=0.005)
     u, ev = _start(case, B, 33, scale=0.002 if name == "uk380" else 0.05)
     cfg = CFG_REF if name != "micro_17x70" else CFG_SMALL
     ref = None
-    for skew in ("0", "1", "2", "3"):
-        monkeypatch.setenv("SEIR_DEBUG_SKEW", skew)
+    for skew in (0, 1, 2, 3):
         with SeirModel(case["cov"], case["init"], max_chains=B) as model:
-            with ChainSampler(model, cfg, B, seed=8, trace_capacity=n) as s:
+            model.set_option(debug_skew=skew)
+            with ChainSampler(model, cfg, B, seed=8, trace_capacity=n, **form) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=eps)
                 tr = s.sample(n)
@@ -304,7 +309,7 @@ def test_results_do_not_depend_on_workgroup_timing(api, monkeypatch, name, B, n,
 
 @pytest.mark.parametrize("name,cfg,eps", [("micro_5x24", CFG_SMALL, 0.002), ("micro_2x2", CFG_SMALL, 0.002),
                                           ("ni11", CFG_REF, 0.002)])
-def test_paired_and_split_agree_over_many_sweeps_with_frequent_conflicts(api, monkeypatch, name, cfg, eps):
+def test_paired_and_split_agree_over_many_sweeps_with_frequent_conflicts(api, name, cfg, eps):
     """Few rows: the speculative E->I proposal collides with the updates accepted before it in a large
     share of the launches, so the re-draw path and every certification rule run hundreds of times."""
     SeirModel, ChainSampler = api
@@ -313,9 +318,8 @@ def test_paired_and_split_agree_over_many_sweeps_with_frequent_conflicts(api, mo
     u, ev = _start(case, B, 41)
     out = {}
     for mode in ("paired", "split"):
-        monkeypatch.setenv("SEIR_MOVES", mode)
         with SeirModel(case["cov"], case["init"], max_chains=B) as model:
-            with ChainSampler(model, cfg, B, seed=5, trace_capacity=n) as s:
+            with ChainSampler(model, cfg, B, seed=5, trace_capacity=n, moves=mode) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=eps)
                 out[mode] = s.sample(n)
@@ -328,7 +332,7 @@ def test_paired_and_split_agree_over_many_sweeps_with_frequent_conflicts(api, mo
     assert sum(int(a.moves[k]["is_accepted"].sum()) for k in a.moves) > 200
 
 
-def test_paired_and_split_launch_forms_agree_at_uk380(api, monkeypatch):
+def test_paired_and_split_launch_forms_agree_at_uk380(api):
     """The paired form (k_move_pair: S->E updates inside the proposing workgroup, speculative E->I
     proposal certified by row comparison, deferred F band) against one-kernel-per-update on the
     BASELINE size, where row conflicts are rare events: the same proposals, decisions and events."""
@@ -338,9 +342,8 @@ def test_paired_and_split_launch_forms_agree_at_uk380(api, monkeypatch):
     u, ev = _start(case, B, 12, scale=0.002)
     out = {}
     for mode in ("paired", "split"):
-        monkeypatch.setenv("SEIR_MOVES", mode)
         with SeirModel(case["cov"], case["init"], max_chains=B) as model:
-            with ChainSampler(model, CFG_REF, B, seed=21, trace_capacity=n) as s:
+            with ChainSampler(model, CFG_REF, B, seed=21, trace_capacity=n, moves=mode) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=1.5e-5)
                 out[mode] = s.sample(n)
@@ -378,26 +381,23 @@ def test_chains_are_independent_of_batch_composition(api):
     assert np.array_equal(tr_all.hmc["target_log_prob"][:, 2], tr_one.hmc["target_log_prob"][:, 0])
 
 
-@pytest.mark.parametrize("B,groups,affinity,graph", [(8, 1, "3", "0"), (8, 1, "0", "0"), (3, 1, "3", "0"), (16, 1, "3", "0"),
-                                                    (8, 2, "3", "0"), (6, 4, "3", "0"), (8, 1, "3", "1"), (6, 2, "3", "1")])
-def test_launch_geometries_give_identical_chains(api, monkeypatch, B, groups, affinity, graph):
+@pytest.mark.parametrize("B,groups,affinity,graph", [(8, 1, 3, 0), (8, 1, 0, 0), (3, 1, 3, 0), (16, 1, 3, 0),
+                                                    (8, 2, 3, 0), (6, 4, 3, 0), (8, 1, 3, 1), (6, 2, 3, 1)])
+def test_launch_geometries_give_identical_chains(api, B, groups, affinity, graph):
     """Block-to-chain mappings (XCD affinity for 1/2/4/8 chains per launch, natural grids
     otherwise, chain groups on separate streams) only move work around: every chain's trace must
     be bit-identical to the same chain run alone, under stream launches and under graph replay."""
-    monkeypatch.setenv("SEIR_CHAIN_GROUPS", str(groups))
-    monkeypatch.setenv("SEIR_XCD_AFFINITY", affinity)
-    monkeypatch.setenv("SEIR_GRAPH", graph)              # stream launches (default) or hipGraph replay
     SeirModel, ChainSampler = api
     case = H.build_case("micro_17x70", 9, alpha_t_sd=0.005)
     u, ev = _start(case, B, 9)
     n = 4
     with SeirModel(case["cov"], case["init"], max_chains=B) as model:
-        with ChainSampler(model, CFG_SMALL, B, seed=5, trace_capacity=n) as s:
+        model.set_option(xcd_affinity=affinity)
+        # stream launches (default) or hipGraph replay; chain groups on separate streams
+        with ChainSampler(model, CFG_SMALL, B, seed=5, trace_capacity=n, chain_groups=groups, use_graph=bool(graph)) as s:
             s.set_state(u, ev)
             s.set_kernel(step_size=0.0004)
             tr_all = s.sample(n)
-    monkeypatch.setenv("SEIR_CHAIN_GROUPS", "1")
-    monkeypatch.setenv("SEIR_GRAPH", "0")
     for b in (0, B - 1):
         with SeirModel(case["cov"], case["init"], max_chains=1) as model:
             with ChainSampler(model, CFG_SMALL, 1, seed=5, first_chain_id=b, trace_capacity=n) as s:

@@ -3,6 +3,7 @@
 #   bash tools/profile_round.sh r01
 # 1. bench.py under rocprofv3 --kernel-trace --stats (per-kernel durations of the timed region)
 # 2. PMC passes, one counter each and nothing else (FETCH_SIZE, WRITE_SIZE) over a short sampler run
+# 2b. MFMA-utilisation counters (SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES, ...) over the stateless evaluation
 # 3. the same FETCH_SIZE pass over the load-only probe with known traffic (calibrates gfx950's unit)
 # Raw output goes to gpurun_out/; tools/summarize_profiles.py condenses it into profiles/.
 set -e
@@ -17,6 +18,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -o k -- python3 tools/quick_sweep_bench.py --groups 1 --sweeps 20 \
       > "$out/pmc_$c.log" 2>&1
 done
+# 2b. matrix-core counters of the stateless evaluation (k_gemm): SQ counters only, in a pass of their own
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES \
+    --output-format csv -d "$out/pmc_mfma" -o k -- python3 tools/quick_eval_bench.py --iters 10 > "$out/pmc_mfma.log" 2>&1 \
+  || echo "MFMA counter pass failed (see $out/pmc_mfma.log): counter names on this ROCm are listed in $out/counters.txt"
+rocprofv3 -L > "$out/counters.txt" 2>&1 || true
 if [ -x tools/probes/se_probe ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_probe" -o k -- tools/probes/se_probe > "$out/pmc_probe.log" 2>&1
 fi

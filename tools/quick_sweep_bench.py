@@ -28,9 +28,8 @@ def main():
     for g in [int(x) for x in args.groups.split(",")]:
         if g > B:
             continue
-        os.environ["SEIR_CHAIN_GROUPS"] = str(g)
         with SeirModel(cov, init, max_chains=B) as model:
-            with ChainSampler(model, cfg, B, seed=1, trace_capacity=args.sweeps) as s:
+            with ChainSampler(model, cfg, B, seed=1, trace_capacity=args.sweeps, chain_groups=g) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=1.2e-5)
                 s.reset_trace(); s.run(10); model.sync()

@@ -20,7 +20,10 @@ import shutil
 import sys
 from collections import defaultdict
 
-DOMINANT = "void seir::k_se<true, 1>"
+# the sampler's gradient kernel: any instance of k_se<GRAD=true, SRC=1, TSM> (the template tail has
+# changed between rounds; the instance with the most launches is the dominant one)
+DOMINANT_PREFIX = "void seir::k_se<true, 1"
+DOMINANT_KEY = "k_se<GRAD=true,SRC=planes>"
 PROBE = "void k_var<1, 8>"
 PROBE_BYTES = 8 * 384 * 384 * 20
 
@@ -62,15 +65,18 @@ def main():
         shutil.copy(stats, os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
     summary = {"source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
                          "passes over tools/quick_sweep_bench.py --groups 1 --sweeps 20 (UK-380 x 365, 8 chains)"}
-    vals = {}
+    vals, names = {}, {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         p = one(os.path.join(raw, f"pmc_{c}", "**", "*counter_collection.csv"))
         if not p:
             continue
         means = counter_means(p)
         write_means(os.path.join(prof, f"{tag}_pmc_{c}.csv"), means)
-        if (DOMINANT, c) in means:
-            vals[c] = means[(DOMINANT, c)][0]
+        cands = [(n, k) for (k, cc), (m, n) in means.items() if cc == c and k.startswith(DOMINANT_PREFIX)]
+        if cands:
+            dominant = max(cands)[1]
+            vals[c] = means[(dominant, c)][0]
+            names[c] = dominant
     factor = None
     p = one(os.path.join(raw, "pmc_probe", "**", "*counter_collection.csv"))
     if p:
@@ -86,9 +92,23 @@ def main():
     if "FETCH_SIZE" in vals:
         f = factor if factor else 2.0
         traffic = vals["FETCH_SIZE"] * 1024.0 * f + vals.get("WRITE_SIZE", 0.0) * 1024.0
-        summary[DOMINANT.replace("void seir::", "")] = {
+        summary[DOMINANT_KEY] = {
+            "kernel_name": names["FETCH_SIZE"].replace("void seir::", ""),
             "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals.get("WRITE_SIZE"),
             "fetch_factor": f, "traffic_bytes_per_launch": traffic}
+    # matrix-core counters of the stateless evaluation (k_gemm): one SQ pass
+    p = one(os.path.join(raw, "pmc_mfma", "**", "*counter_collection.csv"))
+    if p:
+        means = counter_means(p)
+        write_means(os.path.join(prof, f"{tag}_pmc_mfma.csv"), means)
+        mf = {}
+        for (k, c), (m, n) in means.items():
+            if "k_gemm" in k:
+                mf.setdefault(k.replace("void seir::", ""), {})[c] = m
+        if mf:
+            summary["mfma_counters"] = {
+                "source": "rocprofv3 --pmc (SQ counters, own pass) over tools/quick_eval_bench.py (UK-380 x 365, 8 chains)",
+                "per_launch_mean": mf}
     with open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w") as fo:
         json.dump(summary, fo, indent=1)
     print(json.dumps(summary, indent=1))
