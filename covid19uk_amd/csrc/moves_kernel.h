@@ -288,8 +288,11 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
                 const int Dn = D - ((x > 0 && x == kt) ? 1 : 0) + ((x > 0 && kt2 == 0) ? 1 : 0);
                 const long long binc = inc_unbounded ? 0x7fffffffLL : (long long)min_inc + x;
                 const int xmax_r = (int)max(0LL, min((long long)min(s.nmax, kt2 + x), binc));
-                sm.logq_part[j] = (-mv_log((double)Dn, ltab) - mv_log((double)(xmax_r + 1), ltab)) -
-                                  (-mv_log((double)D, ltab) - mv_log((double)(xmax + 1), ltab));
+                // a null sub-move (x == 0) is its own reverse: no correction (see oracle/mcmc_oracle.py,
+                // event_time_move, and tests/test_invariance*.py)
+                sm.logq_part[j] = x > 0 ? (-mv_log((double)Dn, ltab) - mv_log((double)(xmax_r + 1), ltab)) -
+                                              (-mv_log((double)D, ltab) - mv_log((double)(xmax + 1), ltab))
+                                        : 0.0;
                 sm.pend_valid[j] = 1;
                 mv.m[j] = m; mv.a[j] = t; mv.b[j] = t2; mv.dka[j] = -x; mv.dkb[j] = x;
                 mv.lo[j] = min(t, t2); mv.hi[j] = max(t, t2);
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         __syncthreads();
         // test hooks (SEIR_DEBUG_PAIR): 1 = post the token late, 2 = never post it
         if (dbg & 1)
-            for (int i = 0; i < 400; ++i) __builtin_amdgcn_s_sleep(127);
+            for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(127);   // ~0.35 ms: well inside role 0's bounded wait
         if (tid == 0 && !(dbg & 2)) __hip_atomic_store(ch.hand + b, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;

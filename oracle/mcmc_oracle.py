@@ -61,9 +61,23 @@ def _u01(hi, lo):
     return (x.astype(np.float64) + 0.5) * 2.220446049250313e-16
 
 
+def _philox_scalar(c0, c1, c2, c3, k0, k1):
+    """The same ten rounds on Python ints (an order of magnitude faster than NumPy for one counter)."""
+    for _ in range(10):
+        p0, p1 = _M0 * c0, _M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, \
+            ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + _W0) & 0xFFFFFFFF, (k1 + _W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
 def rng_uniform2(seed, chain, sweep, stream, idx):
     """Two uniforms per draw slot; idx may be an array."""
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    if np.ndim(idx) == 0:
+        r = _philox_scalar(int(idx) & 0xFFFFFFFF, int(stream), int(sweep), int(chain), k0, k1)
+        f = lambda hi, lo: ((((hi << 32) | lo) >> 12) + 0.5) * 2.220446049250313e-16   # noqa: E731
+        return np.array([f(r[0], r[1])]), np.array([f(r[2], r[3])])
     r = philox4x32_10(np.atleast_1d(np.asarray(idx, dtype=np.uint64)), stream, sweep, chain, k0, k1)
     return _u01(r[0], r[1]), _u01(r[2], r[3])
 
@@ -236,7 +250,14 @@ class OracleChain:
             Dn = D - (1 if (x > 0 and x == kt) else 0) + (1 if (x > 0 and kt2 == 0) else 0)
             binc = INF if inc == 0 else min_inc + x
             xmax_r = max(0, min(cfg["nmax"], kt2 + x, binc))
-            logq += (-math.log(Dn) - math.log(xmax_r + 1)) - (-math.log(D) - math.log(xmax + 1))
+            # The Hastings correction pairs this sub-move with its reverse (day t2, shift -delta, same x).
+            # A null sub-move (x == 0) leaves the row as it is and is its OWN reverse: correction 0.  (Pairing
+            # it with "x = 0 from day t2" -- a day that may hold no event, i.e. an impossible draw -- would put
+            # the factor (xmax+1)/(xmax_r+1) != 1 into the acceptance of whatever the OTHER rows of the same
+            # proposal do, and the kernel would no longer leave the posterior invariant: found by
+            # tests/test_invariance.py on the enumerated toy.)
+            if x > 0:
+                logq += (-math.log(Dn) - math.log(xmax_r + 1)) - (-math.log(D) - math.log(xmax + 1))
             new[m, t, tgt] -= x
             new[m, t2, tgt] += x
             tr[:, j] = (m, t, delta, x)
@@ -304,7 +325,13 @@ class OracleChain:
 
     # -- one posterior draw --------------------------------------------------
     def sweep_once(self):
-        out = {"hmc": self.hmc_step()}
+        if "hmc" in self.disabled:
+            # a disabled HMC update rejects whatever it proposes; its Philox streams (0, 1) are its own,
+            # so skipping the trajectory changes nothing downstream
+            out = {"hmc": dict(is_accepted=False, target_log_prob=self.logp, step_size=self.eps,
+                               used_step_size=self.eps, log_accept_ratio=float("nan"))}
+        else:
+            out = {"hmc": self.hmc_step()}
         last = {}
         for scan in range(self.cfg["num_event_time_updates"]):
             last["move/S->E"] = self.event_time_move(0, scan, 0)

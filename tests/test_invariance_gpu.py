@@ -1,0 +1,184 @@
+"""Invariant-distribution tests of the HIP sampler through the C-ABI (constructions and rationale:
+tests/invariance_lib.py).  Nothing here compares with the oracle sampler -- the checks are against the
+model itself: the enumerated posterior of a toy, forward simulations by the device simulator
+(seir_simulate), the analytic prior, and the generating parameters of a simulated NI-11 epidemic."""
+import math
+
+import numpy as np
+import pytest
+
+from covid19uk_amd import synth
+from tests import helpers as H
+from tests import invariance_lib as IL
+
+pytestmark = pytest.mark.gpu
+
+CFG_TOY = dict(dmax=2, nmax=2, m=2, occult_nmax=2, num_event_time_updates=3)
+CFG_SMALL = dict(dmax=4, nmax=5, m=2, occult_nmax=4, num_event_time_updates=3)
+CFG_REF = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5)   # example_config.yaml:26-30
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available()
+    import __graft_entry__ as entry
+    entry.build()
+    from covid19uk_amd.seir import SeirModel
+    from covid19uk_amd.sampler import ChainSampler
+    return SeirModel, ChainSampler
+
+
+@pytest.fixture(scope="module")
+def toy():
+    return IL.toy_problem(T=4)
+
+
+@pytest.mark.parametrize("moves", ["paired", "split"])
+@pytest.mark.parametrize("kernel", IL.KERNELS + ("all",))
+def test_event_kernel_leaves_the_enumerated_posterior_invariant(api, toy, kernel, moves):
+    """2 LADs x 4 days, every feasible event tensor tabulated (1892 of them).  Each chain starts from an
+    exact draw of the table; after 3 sweeps x 3 scans of ONE kernel (the others drawn but disabled) the
+    end states of 65536 independent chains are chi-square tested against the table."""
+    SeirModel, ChainSampler = api
+    B, rounds, sweeps = 4096, 16, 3
+    rng = np.random.default_rng(101)
+    u = np.tile(toy["u"], (B, 1))
+    ends, moved = [], 0
+    with SeirModel(toy["cov"], toy["init"], max_chains=B) as model:
+        for rnd in range(rounds):
+            starts = rng.choice(len(toy["prob"]), size=B, p=toy["prob"])
+            with ChainSampler(model, CFG_TOY, B, seed=900 + rnd, trace_capacity=1, record_events=False,
+                              disable=IL.only(kernel), moves=moves) as s:
+                s.set_state(u, toy["states"][starts])
+                lp0 = s.log_prob()
+                assert np.allclose(lp0, toy["logp"][starts], rtol=1e-9, atol=1e-9)
+                s.run(sweeps)
+                _, ev, lp1 = s.get_state()
+            idx = IL.state_indices(toy, ev)
+            assert np.allclose(lp1, toy["logp"][idx], rtol=1e-9, atol=1e-9)   # running log-prob == the table's
+            moved += int((idx != starts).sum())
+            ends.append(idx)
+    ends = np.concatenate(ends)
+    assert moved > 0.1 * len(ends), "the kernel hardly moves: the test would have no power"
+    stat, dof, p = IL.chi_square(ends, toy["prob"])
+    assert p > 1e-3, (kernel, stat, dof, p)
+
+
+@pytest.mark.parametrize("kernel", IL.KERNELS + ("all",))
+def test_event_kernels_preserve_the_joint_distribution_of_simulated_epidemics(api, kernel):
+    """Geweke-style joint test with the device simulator: (z, y) ~ p(. | theta) from seir_simulate, then
+    sweeps of the event kernels given y on 16384 independent chains; 12 moments of (z, y) before and
+    after must agree (paired z-tests)."""
+    SeirModel, ChainSampler = api
+    case = IL.small_population_case()
+    k, th = case["k"], case["theta"]
+    M, T = k.M, k.T
+    B, sweeps = 16384, 4
+    par = np.tile(th[:5], (B, 1))
+    a = th[5] + np.concatenate([[0.0], np.cumsum(th[6:6 + T - 1])])
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        ev0 = model.simulate(par, np.tile(a, (B, 1)), np.tile(th[6 + T - 1:], (B, 1)), k.W, k.weekday_c,
+                             np.tile(case["init"], (B, 1, 1)), seed=77)
+        with ChainSampler(model, CFG_SMALL, B, seed=31, trace_capacity=1, record_events=False,
+                          disable=IL.only(kernel)) as s:
+            s.set_state(np.tile(case["u"], (B, 1)), ev0)
+            s.run(sweeps)
+            _, ev1, _ = s.get_state()
+    # the device simulator against the host one: same model, independent implementations
+    ref = IL.simulate_numpy(case, 4000, np.random.default_rng(1))
+    s_dev, s_ref = IL.event_statistics(ev0, case["init"]), IL.event_statistics(ref, case["init"])
+    zsim = (s_dev.mean(0) - s_ref.mean(0)) / np.sqrt(s_dev.var(0) / len(s_dev) + s_ref.var(0) / len(s_ref))
+    assert np.abs(zsim).max() < 4.5, dict(zip(IL.STAT_NAMES, np.round(zsim, 2)))
+    assert np.array_equal(ev1[..., 2], ev0[..., 2]), "the observed I->R events must never move"
+    assert (ev1 != ev0).any(axis=(1, 2, 3)).mean() > 0.3
+    z = IL.paired_z(s_dev, IL.event_statistics(ev1, case["init"]))
+    assert np.abs(z).max() < 4.5, (kernel, dict(zip(IL.STAT_NAMES, np.round(z, 2))))
+
+
+@pytest.mark.parametrize("hmc", ["chunk", "single"])
+def test_hmc_recovers_the_prior_when_the_likelihood_is_flat(api, hmc):
+    """No infectives, no events: the HMC update targets the prior of model_spec.py:140-198 through the
+    bijector of inference.py:525-535, whose moments are known.  64 chains are 64 independent replicates."""
+    SeirModel, ChainSampler = api
+    case = IL.small_population_case(M=5, T=70)             # T > 64: two day chunks in the chunked leapfrog
+    cov, k = case["cov"], case["k"]
+    M, T, P = k.M, k.T, k.P
+    init = np.stack([k.N, np.zeros(M), np.zeros(M), np.zeros(M)], axis=-1)
+    B, n_adapt, n = 64, 200, 1200
+    var = np.ones(P)
+    var[:6] = (0.5, 0.5, 1.0, 1.0e4, 1.0e4, 100.0)
+    var[6:6 + T - 1] = 0.005 ** 2
+    Qinv = np.linalg.inv(np.diag(cov.adjacency.sum(1)) - 0.25 * cov.adjacency)
+    var[6 + T - 1:] = np.diag(Qinv)
+    cfg = dict(CFG_SMALL, num_event_time_updates=0)
+    with SeirModel(cov, init, max_chains=B) as model:
+        with ChainSampler(model, cfg, B, seed=12, trace_capacity=n, record_events=False, hmc=hmc) as s:
+            s.set_state(np.zeros((B, P)), np.zeros((B, M, T, 3)))
+            s.set_kernel(step_size=0.1, variance=var)
+            s.set_adaptation(adapt_step_size=True, num_adaptation_steps=n_adapt)
+            s.sample(n_adapt, events=False)
+            s.set_adaptation(adapt_step_size=False)
+            tr = s.sample(n, events=False)
+    assert 0.5 < tr.hmc["is_accepted"].mean() < 0.95
+    th = tr.theta                                           # [n, B, P] constrained
+    cm = th.mean(axis=0)                                    # chain means
+    want = np.zeros(P)
+    want[0], want[1] = 0.3, 0.1 * math.sqrt(2.0 / math.pi)  # Gamma(3, rate 10), HalfNormal(0.1)
+    z = (cm.mean(0) - want) / (cm.std(0, ddof=1) / math.sqrt(B))
+    assert np.abs(z).max() < 4.8, (int(np.abs(z).argmax()), float(np.abs(z).max()))
+    v = th.reshape(-1, P).var(axis=0)
+    vwant = np.concatenate([[0.03, 0.01 * (1 - 2 / math.pi), 1.0, 1.0e4, 1.0e4, 100.0],
+                            np.full(T - 1, 0.005 ** 2), np.diag(Qinv)])
+    assert np.abs(v / vwant - 1).max() < 0.12, (int(np.abs(v / vwant - 1).argmax()), v / vwant)
+    # the CAR prior couples the spatial effects: their covariance is Q^-1, not just its diagonal
+    sp = th[:, :, 6 + T - 1:].reshape(-1, M)
+    assert np.abs(np.cov(sp.T) - Qinv).max() < 0.08 * np.abs(Qinv).max()
+
+
+def test_posterior_recovers_the_generating_parameters_on_ni11(api):
+    """The whole schedule of run_mcmc (inference.py:303-470: 1825 warm-up draws, then bursts) on NI-11
+    epidemics simulated from known parameters, 4 chains each.  One data set cannot
+    separate a biased sampler from an unlucky draw (six 95 % intervals miss at least once in a quarter
+    of all perfectly calibrated runs), so six independent epidemics are analysed: the generating value of
+    every global parameter must sit inside its central 95 % interval in at least 31 of the 36 cases, and
+    no parameter's posterior z-score may be off in the same direction across the data sets."""
+    SeirModel, ChainSampler = api
+    from covid19uk_amd.inference import inference as inf
+    cov = synth.make_covariates("ni11")
+    M, T = cov.M, cov.T
+    P = 6 + T - 1 + M
+    B, D = 4, 6
+    cfg = dict(CFG_REF, num_bursts=8, num_burst_samples=500)
+    names = ("psi", "sigma_space", "beta_area", "gamma0", "gamma1", "alpha_0")
+
+    class Collect:
+        def __init__(self):
+            self.theta = []
+
+        def write_samples(self, d, first_dim_offset=0):
+            self.theta.append(np.stack([d[n] for n in names], 1))
+
+        def write_results(self, d, first_dim_offset=0):
+            pass
+
+    z, inside = np.zeros((D, 6)), np.zeros((D, 6), dtype=bool)
+    for ds in range(D):
+        events, init, truth = synth.simulate_epidemic(cov, seed=1000 + ds)
+        posts = [Collect() for _ in range(B)]
+        with SeirModel(cov, init, max_chains=B) as model:
+            with ChainSampler(model, cfg, B, seed=4 + ds, trace_capacity=800) as s:
+                s.set_state(np.zeros((B, P)), np.stack([events] * B))      # inference.py:563-573: u0 = 0
+                inf.run_mcmc(s, cfg, posts, log=open("/dev/null", "w"))
+        draws = np.stack([np.concatenate(p.theta)[inf.warmup_size():] for p in posts])     # [B, n, 6]
+        assert draws.shape[1] == 4000
+        pooled = draws.reshape(-1, 6)
+        lo, hi = np.percentile(pooled, [2.5, 97.5], axis=0)
+        tv = np.array([truth[n] for n in names])
+        z[ds] = (tv - pooled.mean(0)) / pooled.std(0)
+        inside[ds] = (lo <= tv) & (tv <= hi)
+    assert inside.sum() >= 31, (inside.sum(), dict(zip(names, inside.sum(0))))
+    drift = z.mean(0) * math.sqrt(D)
+    # psi and sigma_space are pulled towards their informative priors (Gamma(3,10), HalfNormal(0.1)): allow
+    # for that shrinkage; the flat-prior parameters must be centred
+    assert np.abs(drift).max() < 3.5, dict(zip(names, np.round(drift, 2)))

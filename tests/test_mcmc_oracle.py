@@ -101,13 +101,41 @@ def test_event_time_move_log_q_ratio_is_reverse_minus_forward(chain):
             pd = out["proposed_delta"]
             for j in range(pd.shape[1]):
                 m, t, delta, x = (int(v) for v in pd[:, j])
-                if delta == 0:
+                if delta == 0 or x == 0:       # a null sub-move is its own reverse: no correction
                     continue
                 want += logq_time_move(k, CFG, new, tgt, m, t + delta, -delta, x) \
                     - logq_time_move(k, CFG, before, tgt, m, t, delta, x)
             assert abs(out["log_q_ratio"] - want) < 1e-12, (sweep, tgt, out["log_q_ratio"], want)
             n_checked += 1
     assert n_checked > 40
+
+
+def test_null_sub_move_carries_no_correction():
+    """Two rows per proposal: when one row draws x = 0 (nothing moves there) the acceptance of what the
+    OTHER row does must not pick up a factor from it.  The first version paired the null sub-move with
+    "x = 0 from the arrival day" -- a different bound, possibly an empty day -- and the kernel then did
+    not leave the posterior invariant (caught by tests/test_invariance*.py on the enumerated toy)."""
+    c = H.build_case("micro_5x24", 3)
+    k = c["k"]
+    hits = 0
+    for chain_id in range(40):
+        ch = mo.OracleChain(k, CFG, c["u"], c["events"], seed=99, chain_id=chain_id)
+        for tgt in (0, 1):
+            before = ch.events.copy()
+            out = ch.event_time_move(tgt, 0, tgt)
+            pd = out["proposed_delta"]
+            xs = [int(v) for v in pd[3]]
+            if not out["valid"] or 0 not in xs or max(xs) == 0:
+                continue
+            want = 0.0
+            for j in range(pd.shape[1]):
+                m, t, delta, x = (int(v) for v in pd[:, j])
+                if x > 0:
+                    want += logq_time_move(k, CFG, out["proposed_events"], tgt, m, t + delta, -delta, x) \
+                        - logq_time_move(k, CFG, before, tgt, m, t, delta, x)
+            assert abs(out["log_q_ratio"] - want) < 1e-12
+            hits += 1
+    assert hits >= 3
 
 
 def test_occult_log_q_ratio_is_reverse_minus_forward(chain):
