@@ -71,6 +71,8 @@ struct Work {
     int2 *KS;              // [B][Mp][Tp]
     int *K[3], *St[3];     // sampler planes [B][Mp][Tp] (null on a plain context)
     int *rowtot;           // [B][2][Mp] row totals of S->E / E->I events (sampler)
+    int *rngtot;           // [B][2][Mp] the same inside the occult range [tr_lo, tr_hi) (sampler): kept up to date
+                           //            by every accepted update, so a proposal reads one int per row instead of 21
     double *rowconst;      // [B][Mp]
     double *colIR;         // [B][nrb_scan][Tp][2]
     double *Kir, *Dir;     // [B][Tp]  sum_m k_ir, sum_m (I - k_ir)

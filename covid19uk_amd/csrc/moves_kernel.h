@@ -423,28 +423,10 @@ __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg
     lds_barrier();
 }
 
-// row totals of the target transition inside the occult range, for every row, into LDS
+// events of the target transition inside the occult range, for every row, into LDS (M beyond the prefetch width)
 __device__ __forceinline__ void range_totals_to_lds(const Dims &d, const Work &w, const SamplerCfg &s, int b, int tgt,
                                                     int *rg) {
-    const int R = s.tr_hi - s.tr_lo, n = d.M * R;
-    for (int m = threadIdx.x; m < d.M; m += MVB) rg[m] = 0;
-    lds_barrier();
-    for (int base = threadIdx.x; base < n; base += MVB * MVU) {
-        int v[MVU], row[MVU];
-#pragma unroll
-        for (int k = 0; k < MVU; ++k) {
-            const int idx = base + k * MVB;
-            v[k] = 0; row[k] = 0;
-            if (idx < n) {
-                const int m = idx / R, t = s.tr_lo + idx - m * R;
-                row[k] = m;
-                v[k] = w.K[tgt][((size_t)b * d.Mp + m) * d.Tp + t];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < MVU; ++k)
-            if (v[k]) atomicAdd(&rg[row[k]], v[k]);
-    }
+    for (int m = threadIdx.x; m < d.M; m += MVB) rg[m] = w.rngtot[((size_t)b * 2 + tgt) * d.Mp + m];
     __syncthreads();
 }
 
@@ -489,16 +471,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
             if (next.kind == 0) {
                 rt_pre[k] = w.rowtot[((size_t)b * 2 + next.tgt) * d.Mp + m];
             } else {
-                const int *kr = w.K[next.tgt] + ((size_t)b * d.Mp + m) * d.Tp + s.tr_lo;
-                int acc = 0;
-                for (int t0 = 0; t0 < R; t0 += 32) {           // one batch at the reference's 21-day range
-                    int v[32];
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) v[j] = t0 + j < R ? kr[t0 + j] : 0;
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) acc += v[j];
-                }
-                rt_pre[k] = acc;
+                rt_pre[k] = w.rngtot[((size_t)b * 2 + next.tgt) * d.Mp + m];
             }
         }
     }
@@ -564,6 +537,9 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
                         w.K[mv.tgt][rowoff + mv.a[i]] += mv.dka[i];
                         if (mv.b[i] >= 0) w.K[mv.tgt][rowoff + mv.b[i]] += mv.dkb[i];
                         w.rowtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += mv.dka[i] + mv.dkb[i];
+                        const int ra = (mv.a[i] >= s.tr_lo && mv.a[i] < s.tr_hi) ? mv.dka[i] : 0;
+                        const int rb = (mv.b[i] >= s.tr_lo && mv.b[i] < s.tr_hi) ? mv.dkb[i] : 0;
+                        if (ra + rb != 0) w.rngtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += ra + rb;
                     }
                     __syncthreads();     // two updates may touch the same Dir[t]
                 }
@@ -666,7 +642,7 @@ constexpr int PRE_RT = 4;                                      // prefetched row
 // row totals (kind 0) or per-row events inside the occult range (kind 1) of plane spec.tgt
 __device__ __forceinline__ void mv_prefetch_rows(const Dims &d, const Work &w, const SamplerCfg &s, int b, MoveSpec spec,
                                                  bool on, int (&pre)[PRE_RT]) {
-    const int tid = threadIdx.x, R = s.tr_hi - s.tr_lo;
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < PRE_RT; ++k) {
         const int m = tid + k * MVB;
@@ -675,16 +651,7 @@ __device__ __forceinline__ void mv_prefetch_rows(const Dims &d, const Work &w, c
             if (spec.kind == 0) {
                 pre[k] = w.rowtot[((size_t)b * 2 + spec.tgt) * d.Mp + m];
             } else {
-                const int *kr = w.K[spec.tgt] + ((size_t)b * d.Mp + m) * d.Tp + s.tr_lo;
-                int acc = 0;
-                for (int t0 = 0; t0 < R; t0 += 32) {           // one batch at the reference's 21-day range
-                    int v[32];
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) v[j] = t0 + j < R ? kr[t0 + j] : 0;
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) acc += v[j];
-                }
-                pre[k] = acc;
+                pre[k] = w.rngtot[((size_t)b * 2 + spec.tgt) * d.Mp + m];
             }
         }
     }
@@ -727,7 +694,7 @@ __device__ __forceinline__ void mv_rows_to_lds(const Dims &d, const Work &w, con
 
 // state update of an accepted proposal by the calling block (rows, events, row totals, I->R
 // exposure); ends with the stores drained
-__device__ __forceinline__ void mv_apply_rows(const Dims &d, const Work &w, int b, const Move &mv) {
+__device__ __forceinline__ void mv_apply_rows(const Dims &d, const Work &w, const SamplerCfg &s, int b, const Move &mv) {
     const int tid = threadIdx.x;
     for (int i = 0; i < mv.n; ++i) {
         const size_t rowoff = ((size_t)b * d.Mp + mv.m[i]) * d.Tp;
@@ -741,6 +708,9 @@ __device__ __forceinline__ void mv_apply_rows(const Dims &d, const Work &w, int 
             w.K[mv.tgt][rowoff + mv.a[i]] += mv.dka[i];
             if (mv.b[i] >= 0) w.K[mv.tgt][rowoff + mv.b[i]] += mv.dkb[i];
             w.rowtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += mv.dka[i] + mv.dkb[i];
+            const int ra = (mv.a[i] >= s.tr_lo && mv.a[i] < s.tr_hi) ? mv.dka[i] : 0;
+            const int rb = (mv.b[i] >= s.tr_lo && mv.b[i] < s.tr_hi) ? mv.dkb[i] : 0;
+            if (ra + rb != 0) w.rngtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += ra + rb;
         }
         __syncthreads();     // two updates may touch the same cells
     }
@@ -926,7 +896,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
             if (pend_acc && mv.any_dI) { *fp = mv; fp->valid = 1; }
             else fp->valid = 0;
         }
-        if (pend_acc) mv_apply_rows(d, w, b, mv);
+        if (pend_acc) mv_apply_rows(d, w, s, b, mv);
         if (tid == 0) {
             if (pend_acc) {
                 double *hs = ch.hs + (size_t)b * NHS;
@@ -959,7 +929,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         lds_barrier();
         se_acc = s_acc_se != 0;
         if (se_acc && !waited) { wait_role1(); waited = true; }
-        if (se_acc) mv_apply_rows(d, w, b, mv);
+        if (se_acc) mv_apply_rows(d, w, s, b, mv);
         if (tid == 0) {
             if (se_acc) {
                 double *hs = ch.hs + (size_t)b * NHS;

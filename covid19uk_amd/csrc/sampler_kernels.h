@@ -1248,11 +1248,32 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
 // End of sweep: record the event tensor in the reference's [M][T][3] order.  One wave per row,
 // lanes over days (coalesced plane reads, no index division); grid (ceil(M/4), B).
 // `advanced`: the sweep counter was already incremented by the closing k_move_pa2.
-__global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Chains ch, int advanced) {
+// apply_f (paired form): each wave first writes the F band of the sweep's last accepted E->I update
+// (Chains::fpend) for its row, which saves the separate k_apply_fpend launch.
+__global__ __launch_bounds__(256) void k_record(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int advanced, int apply_f) {
+    __shared__ Move fp;
     debug_skew(d);
     const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + wave;
     const unsigned slot = ch.sweep[b] - (unsigned)advanced - ch.slot0[0];
+    if (apply_f) {                                           // uniform
+        if (threadIdx.x == 0) fp = ch.fpend[b];
+        __syncthreads();
+        if (fp.valid == 1 && m < d.M) {
+            double coef[MMAX];
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                coef[i] = i < fp.n ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + m] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+            double *Fr = w.F + ((size_t)b * d.Mp + m) * d.Tp;
+            for (int t = fp.LO + lane; t <= fp.HI; t += WAVE) {
+                double dF = 0.0;
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dF += coef[i];
+                if (dF != 0.0) Fr[t] += dF;
+            }
+        }
+    }
     if (slot >= (unsigned)s.cap || m >= d.M) return;
     int *out = ch.tr_events + (((size_t)slot * s.B + b) * d.M + m) * d.T * 3;
     const size_t q0 = ((size_t)b * d.Mp + m) * d.Tp;
@@ -1271,6 +1292,23 @@ __global__ __launch_bounds__(256) void k_record(Dims d, Work w, SamplerCfg s, Ch
             const int t = t0 + j * WAVE + lane;
             if (t < d.T) { out[t * 3 + 0] = k0[j]; out[t * 3 + 1] = k1[j]; out[t * 3 + 2] = k2[j]; }
         }
+    }
+}
+
+// Events of planes 0 and 1 inside the occult range, per row (state (re)load; afterwards every accepted
+// update keeps Work::rngtot current).  One wave per row; grid (ceil(M/4), B).
+__global__ __launch_bounds__(256) void k_range_totals(Dims d, Work w, SamplerCfg s) {
+    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= d.M) return;
+    const size_t q0 = ((size_t)b * d.Mp + m) * d.Tp;
+    int a0 = 0, a1 = 0;
+    for (int t = s.tr_lo + lane; t < s.tr_hi; t += WAVE) { a0 += w.K[0][q0 + t]; a1 += w.K[1][q0 + t]; }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+        w.rngtot[((size_t)b * 2 + 0) * d.Mp + m] = a0;
+        w.rngtot[((size_t)b * 2 + 1) * d.Mp + m] = a1;
     }
 }
 

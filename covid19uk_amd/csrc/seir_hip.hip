@@ -717,7 +717,7 @@ extern "C" void seir_sampler_destroy(seir_sampler *s) {
     for (void *p : s->allocs) (void)hipFree(p);
     Work &w = s->ctx->w;
     for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
-    w.rowtot = nullptr;
+    w.rowtot = w.rngtot = nullptr;
     w.TS = w.sp = w.gst = w.Vt = w.acur = w.rirc = w.CT = nullptr;
     delete s;
 }
@@ -780,6 +780,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
 #define S_ALLOC(ptr, n) if (!rc) rc = s_alloc(s, &(ptr), (n))
     for (int x = 0; x < 3; ++x) { S_ALLOC(w.K[x], cells); S_ALLOC(w.St[x], cells); }
     S_ALLOC(w.rowtot, (size_t)ctx->Bmax * 2 * d.Mp);
+    S_ALLOC(w.rngtot, (size_t)ctx->Bmax * 2 * d.Mp);
     S_ALLOC(w.TS, (size_t)ctx->Bmax * d.nmt * d.ntc * 4);
     S_ALLOC(w.sp, (size_t)ctx->Bmax * 2 * d.Mp);
     S_ALLOC(w.gst, (size_t)ctx->Bmax * 2 * GST_N);
@@ -837,6 +838,7 @@ static void enqueue_refresh(seir_sampler *s) {
     const Dims &d = ctx->d;
     const int B = s->cfg.B;
     launch_scan<1>(ctx, whole(ctx, B), nullptr);
+    hipLaunchKernelGGL(k_range_totals, dim3((d.M + 3) / 4, B), dim3(256), 0, ctx->stream, d, ctx->w, s->cfg);
     launch_colreduce(ctx, whole(ctx, B));
     launch_gemm(ctx, whole(ctx, B));
     hipLaunchKernelGGL(k_chain_tables, dim3(B), dim3(256), 0, ctx->stream, d, ctx->c, ctx->w, s->ch);
@@ -1085,7 +1087,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
     // per update [finalize previous | propose] then the log-ratio over the touched cells
     Dims d = l.d;
-    int advanced = 0;
+    int advanced = 0, fpend_in_record = 0;
     {
         const bool aff = (l.affinity & 2) && xcd_affinity_applies(c.nrb_d, nb);
         d.aff_nb = aff ? nb : 0;
@@ -1109,7 +1111,9 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
                 hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, 1,
                                    pbuf, nb, 62, 0);
-                hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
+                // the F band of the last accepted E->I update: by k_record's waves when it runs anyway
+                if (s->record_events) fpend_in_record = 1;
+                else hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
                 advanced = 1;
             }
         } else {
@@ -1132,7 +1136,8 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     }
     d.aff_nb = 0;
     if (s->record_events)
-        hipLaunchKernelGGL(k_record, dim3((d.M + 3) / 4, nb), dim3(256), 0, st, d, ctx->w, c, s->ch, advanced);
+        hipLaunchKernelGGL(k_record, dim3((d.M + 3) / 4, nb), dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, advanced,
+                           fpend_in_record);
     if (!advanced) hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);
 }
 

@@ -5,7 +5,6 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsei
 from covid19uk_amd import synth
 from covid19uk_amd.sampler import ChainSampler
 from covid19uk_amd.seir import SeirModel
-os.environ["SEIR_NO_GRAPH"] = "1"
 cfg = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=int(os.environ.get("NSCAN", "0")))
 cov = synth.make_covariates("uk380")
 events, init, truth = synth.simulate_epidemic(cov)
@@ -32,17 +31,7 @@ with SeirModel(cov, init, max_chains=B) as model:
             print("k_move_pair block 0 (se slot", int(os.environ.get("STAMP_SLOT", "1")) & 2, "): entry+finalize", (st[1]-st[0])*10, "se tables", (st[2]-st[1])*10,
                   "se propose", (st[3]-st[2])*10, "se delta", (st[4]-st[3])*10, "se accept/apply/trace", (st[5]-st[4])*10,
                   "nx tables", (st[6]-st[5])*10, "nx propose+store", (st[7]-st[6])*10, "ns; total", (st[7]-st[0])*10)
-            print("k_move_pa2 block 0, slot", os.environ.get("STAMP_SLOT", "1"), ": entry->sums", (st[1]-st[0])*10, "finalize", (st[2]-st[1])*10,
-                  "tables", (st[3]-st[2])*10, "propose: rng/init", (st[4]-st[3])*10, "select rows", (st[5]-st[4])*10,
-                  "stage rows", (st[6]-st[5])*10, "select days", (st[7]-st[6])*10, "mins", (st[8]-st[7])*10,
-                  "finish lanes", (st[9]-st[8])*10, "compact", (st[10]-st[9])*10, "store", (st[11]-st[10])*10,
-                  "ns ; total", (st[11]-st[0])*10)
             print("k_move_delta block", os.environ.get("STAMP_BLOCK", "0"), ": mv+ltab", (st[13]-st[12])*10, "band", (st[14]-st[13])*10,
                   "own rows", (st[15]-st[14])*10, "ns")
-            names = []
-            for i, v in enumerate(st):
-                v = int(v)
-                print(f"scan {i // 4} {names[i % 4]}: propose {(v & 0xfffff) / 100:.2f} us, delta {((v >> 20) & 0xfffff) / 100:.2f} us, "
-                      f"apply {((v >> 40) & 0xfffff) / 100:.2f} us, acc {(v >> 60) & 1} valid {(v >> 61) & 1}")
         tr = s.read_trace(3, events=False)
         print("accepts", {k: v["is_accepted"][-1].astype(int).tolist() for k, v in tr.moves.items()})
