@@ -730,101 +730,111 @@ __device__ __forceinline__ void mv_trace(const SamplerCfg &s, const Chains &ch, 
     }
 }
 
-// The pending E->I-type descriptor is either the speculative one (Chains::mv[buf]) or, when the
-// authoritative workgroup found a row conflict, the one it re-drew (Chains::mvfix, Chains::mvsel = 1).
-// Both are fetched in one round trip; returns the one to use.  Ends with a barrier.
-__device__ __forceinline__ const Move &load_pending(const SamplerCfg &s, const Chains &ch, int b, int buf, Move &A,
-                                                    Move &Bm, int &sel) {
-    if (threadIdx.x == 0) A = ch.mv[(size_t)buf * s.B + b];
-    if (threadIdx.x == 64) Bm = ch.mvfix[(size_t)buf * s.B + b];
-    if (threadIdx.x == 65) sel = ch.mvsel[(size_t)buf * s.B + b];
-    __syncthreads();
-    return sel ? Bm : A;
-}
-
-// sum of k_move_delta's partial log-ratios and the accept decision of the pending proposal
-// (every thread returns the same values)
-__device__ __forceinline__ bool pending_accept(const SamplerCfg &s, const Chains &ch, int b, int buf, int sel,
-                                               const Move &pend, double *red, double &dth, double &dcn) {
-    dth = 0.0; dcn = 0.0;
-    for (int i = threadIdx.x; i < s.nrb_d; i += MVB) {
-        dth += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
-        dcn += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
-    }
-    mv_sum2(dth, dcn, red);
-    const double *od = ch.Down + (((size_t)buf * 2 + (sel ? 1 : 0)) * s.B + b) * 2;   // the updated rows' part
-    dth += od[0];
-    dcn += od[1];
-    const double ratio = dth + dcn + pend.logq;
-    return pend.valid && pend.logu < ratio;                  // NaN -> reject
-}
-
-// log-ratio of a drawn E->I-type proposal over the rows it updates -> Chains::Down[parity][which][chain]
-__device__ __forceinline__ void mv_own_rows_to_down(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
-                                                    const Chains &ch, int b, const Move &mv, double psi,
-                                                    const double2 *ltab, const Move *fp, double *red, int parity,
-                                                    int which) {
+// log-ratio of a drawn proposal over the rows it updates -> od[0..1] = {theta part, constant part}
+__device__ __forceinline__ void mv_own_rows_to_down(const Dims &d, const Consts &c, const Work &w, int b, const Move &mv,
+                                                    double psi, const double2 *ltab, const Move *fp, double *red,
+                                                    double *od) {
     double dth = 0.0, dcn = 0.0;
     if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, d.M, ltab, dth, dcn, fp);
     mv_sum2(dth, dcn, red);
     if (threadIdx.x == 0) {
-        double *od = ch.Down + (((size_t)parity * 2 + which) * s.B + b) * 2;
         od[0] = dth;
         od[1] = dcn;
     }
 }
 
-// grid (2 B) x MVB threads: block id = role * B + chain.
+// What the authoritative workgroup leaves for the next launch about the pre-drawn S->E-type proposal
+// (Chains::prev, double-buffered by launch parity): whether the proposal may be used at all, and the rows
+// the pending E->I-type update changed while the pre-draw was reading the planes.
+struct PairNote {
+    int ok;                           // 1: nothing in this launch invalidated the pre-drawn proposal outright
+    int n, rows[MMAX];                // rows of the E->I-type update accepted in this launch
+};
+
+// grid (R B) x MVB threads, R = 1..3 roles:
 //   role 0, the authoritative workgroup of the chain: (1) finalize the pending E->I-type proposal,
-//     (2) the whole S->E-type update, (3) certify the speculative E->I proposal of role 1 -- its rows
-//     depend on the row totals and the uniforms only, so role 0 recomputes just those; the proposal
-//     is valid unless one of its rows was changed in (1) or (2) (then role 0 draws it again from the
-//     final state into Chains::mvfix and sets Chains::mvsel).
-//   role 1: draws the E->I-type proposal from the state at entry, concurrently with role 0's work.
-//     It has no side effect besides Chains::mv[pbuf^1] and Chains::Down.  What it reads is of two kinds:
-//     rows of the planes -- if role 0 writes one of them in (1) or (2) it is a row of a conflict, which
-//     role 0 detects on its own; and the plane's row/range totals, fetched at entry -- role 0 does not
-//     write anything before role 1 has them (one-word handshake, Chains::hand; if role 1 is not
-//     there in time role 0 goes on and re-draws the proposal itself).
+//     (2) the S->E-type update `se` -- from the proposal and own-rows log-ratio PRE-DRAWN by role 2 of the
+//     previous launch when nothing invalidated them, otherwise drawn here -- (3) certify the speculative
+//     E->I proposal of role 1: its rows depend on the row totals and the uniforms only, so role 0
+//     recomputes just those; the proposal is valid unless one of its rows was changed in (1) or (2) (then
+//     role 0 draws it again from the final state into Chains::mvfix and sets Chains::mvsel).
+//   role 1: draws the E->I-type proposal `next` from the state at entry, concurrently with role 0's work.
+//     It has no side effect besides Chains::mv[pbuf^1] and Chains::Down.
+//   role 2: draws the S->E-type proposal `se_next` of the NEXT launch from the state at entry, and its
+//     log-ratio over the rows it updates (Chains::mvs / Chains::DownS[pbuf^1]).  An S->E-type proposal reads
+//     only its own rows and the S->E plane's row (or occult-range) totals, so it is still the proposal the
+//     next launch would draw unless (a) this launch's own S->E-type update is accepted (the totals of the
+//     plane may move), (b) one of its rows is a row of an E->I-type update accepted in between (the pending
+//     one of this launch or the one finalized at the start of the next), or (c) this workgroup was late.
+//     (a)-(c) are all decided by role 0 without looking at role 2's output; the next launch then draws the
+//     update itself, exactly as before.  If the E->I-type update finalized at the start of the next launch
+//     is accepted, F moved under the proposal's rows and only the log-ratio is recomputed.
+//   What the speculative roles read is of two kinds: rows of the planes -- if role 0 writes one of them it
+//     is a row of a conflict, which role 0 detects on its own -- and the planes' row/range totals, fetched
+//     at entry: role 0 does not write anything before roles 1 and 2 hold them (one-word handshakes,
+//     Chains::hand / hand2; if a role is not there in time role 0 goes on and discards its output).
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
-                                                   MoveSpec next, int have_prev, int pbuf, int nbk, int lidx, int dbg) {
+                                                   MoveSpec next, MoveSpec se_next, int have_prev, int have_pre,
+                                                   int pbuf, int nbk, int lidx, int dbg) {
     extern __shared__ int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
+    __shared__ PairNote note;
+    __shared__ double pre_down[2], s_down[4];
     __shared__ double2 ltab[LDSTAB_N];
-    __shared__ int s_sel, s_acc_se, s_conf, s_late;
+    __shared__ int s_sel, s_acc_se, s_conf, s_late, s_late2, s_use_pre;
     debug_skew(d);
-    // block id = (1 - role) * nbk + chain: the speculative workgroups (role 1) have the lower ids and are
-    // dispatched first, so an authoritative workgroup never holds a CU waiting for a partner that has
-    // not been placed yet, whatever the number of chains; the closing launch has role 0 only
-    const int half = (int)blockIdx.x / nbk;
-    const int role = gridDim.x > (unsigned)nbk ? 1 - half : 0;
-    const int b = d.b0 + (int)blockIdx.x - half * nbk, tid = threadIdx.x;
+    // block id = slot * nbk + chain with the speculative roles in the low slots: they are dispatched first,
+    // so an authoritative workgroup never holds a CU waiting for a partner that has not been placed yet,
+    // whatever the number of chains; the closing launch has role 0 only
+    const int nroles = (int)gridDim.x / nbk, slot = (int)blockIdx.x / nbk;
+    const int role = slot == nroles - 1 ? 0 : slot + 1;
+    const int b = d.b0 + (int)blockIdx.x - slot * nbk, tid = threadIdx.x;
     const int M = d.M, T = d.T;
-    const bool do_se = role == 0 && se.kind >= 0, do_nx = next.kind >= 0;
+    const bool do_se = role == 0 && se.kind >= 0, do_nx = next.kind >= 0, do_pre = se_next.kind >= 0 && nroles == 3;
     if (role == 1 && !do_nx) return;
+    if (role == 2 && !do_pre) return;
 #ifdef SEIR_STAMPS
     double *stamp_hs = ch.hs + (size_t)b * NHS;
     const bool stamp_on = do_se && b == 0 && se.slot == (SEIR_STAMP_SLOT & 2) && se.scan == 0;
 #define PSTAMP(i) do { if (threadIdx.x == 0 && stamp_on) ((unsigned long long *)(stamp_hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef SEIR_STAMP_ROLE
+#define SEIR_STAMP_ROLE 1
+#endif
+    // a speculative role's phases (slots 8..11): role SEIR_STAMP_ROLE of chain 0 in the launch whose S->E slot matches
+    const bool rstamp_on = role == SEIR_STAMP_ROLE && b == 0 && se.slot == (SEIR_STAMP_SLOT & 2) && se.scan == 0;
+#define RSTAMP(i) do { if (threadIdx.x == 0 && rstamp_on) ((unsigned long long *)(stamp_hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PSTAMP(i) do {} while (0)
+#define RSTAMP(i) do {} while (0)
 #endif
     PSTAMP(0);
+    RSTAMP(8);
     // ---- entry: everything that does not depend on a decision made in this launch
     const bool pre_ok = M <= PRE_RT * MVB;
+    const MoveSpec &mine = role == 2 ? se_next : next;          // the proposal a speculative role draws
     int pre_se[PRE_RT], pre_nx[PRE_RT];
     mv_prefetch_rows(d, w, s, b, se, do_se && pre_ok, pre_se);
-    mv_prefetch_rows(d, w, s, b, next, do_nx && pre_ok, pre_nx);
+    mv_prefetch_rows(d, w, s, b, mine, (role == 2 || do_nx) && pre_ok, pre_nx);
     const unsigned token = ch.sweep[b] * 64u + (unsigned)lidx + 1u;       // unique per (sweep, launch): lidx < 63
-    if (role == 1) {
-        // the totals are in registers: tell role 0 it may start writing
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // test hooks (SEIR_DEBUG_PAIR): 1 = post the token late, 2 = never post it
-        if (dbg & 1)
-            for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(127);   // ~0.35 ms: well inside role 0's bounded wait
-        if (tid == 0 && !(dbg & 2)) __hip_atomic_store(ch.hand + b, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // ... all of it issued before the first wait: the pending descriptors, k_move_delta's partial sums, the
+    // own-rows parts, the pre-drawn proposal and its note -- one round trip for the whole entry
+    double dth0 = 0.0, dcn0 = 0.0;
+    if (have_prev) {
+        move_copy(&pendA, ch.mv + (size_t)pbuf * s.B + b, 64);
+        move_copy(&pendB, ch.mvfix + (size_t)pbuf * s.B + b, 128);
+        if (tid == 192) s_sel = ch.mvsel[(size_t)pbuf * s.B + b];
+        if (tid >= 196 && tid < 200) s_down[tid - 196] = ch.Down[(((size_t)pbuf * 2 + ((tid - 196) >> 1)) * s.B + b) * 2 + ((tid - 196) & 1)];
+        for (int i = tid; i < s.nrb_d; i += MVB) {
+            dth0 += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
+            dcn0 += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
+        }
+    }
+    const bool pre_avail = do_se && have_pre;
+    if (pre_avail) {
+        move_copy(&sm_se.mv, ch.mvs + (size_t)pbuf * s.B + b, 256);
+        if (tid == 320) note = ch.prev[(size_t)pbuf * s.B + b];
+        if (tid == 321 || tid == 322) pre_down[tid - 321] = ch.DownS[((size_t)pbuf * s.B + b) * 2 + (tid - 321)];
     }
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
     unsigned tr_slot = 0xffffffffu;
@@ -834,9 +844,20 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         hs_th = hs[HS_LP_THETA]; hs_cn = hs[HS_LP_CONST];
         tr_slot = ch.sweep[b] - ch.slot0[0];
     }
-    if (do_se || do_nx) psi = w.scal[(size_t)b * NSCAL + SC_PSI];
-    if (do_se) mv_draw(s, ch, b, se, sm_se, T);
-    if (do_nx) mv_draw(s, ch, b, next, sm_nx, T);
+    psi = w.scal[(size_t)b * NSCAL + SC_PSI];
+    if (role != 0) {
+        // the totals are in registers: tell role 0 it may start writing
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // test hooks (seir_sampler_desc::debug_pair): 1 = role 1 posts its token late, 2 = never; 4 / 8: role 2
+        const int late_bit = role == 1 ? 1 : 4, absent_bit = role == 1 ? 2 : 8;
+        if (dbg & late_bit)
+            for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(127);   // ~0.35 ms: well inside role 0's bounded wait
+        if (tid == 0 && !(dbg & absent_bit))
+            __hip_atomic_store((role == 1 ? ch.hand : ch.hand2) + b, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (do_se && !pre_avail) mv_draw(s, ch, b, se, sm_se, T);
+    if (role != 0 || do_nx) mv_draw(s, ch, b, mine, sm_nx, T);
     MvLds L{};
     int *rtl = dyn_i + M;
     L.rt = rtl;
@@ -844,58 +865,77 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     L.rk = dyn_i + 2 * M;
     L.rsrc = L.rk + MMAX * (T + 1);
     L.rdst = L.rsrc + MMAX * (T + 1);
-    // ---- (1) the pending E->I-type proposal: both roles need the decision, role 0 acts on it
+    // ---- (1) the pending E->I-type proposal: every role needs the decision, role 0 acts on it
     bool pend_acc = false;
-    double dth0 = 0.0, dcn0 = 0.0;
     const Move *pendp = nullptr;
     if (have_prev) {
-        const Move &pend = load_pending(s, ch, b, pbuf, pendA, pendB, s_sel);
+        __syncthreads();                                   // the descriptors fetched at entry are in LDS
+        const Move &pend = s_sel ? pendB : pendA;          // speculative one, or re-drawn after a row conflict
         pendp = &pend;
-        pend_acc = pending_accept(s, ch, b, pbuf, s_sel, pend, sm_nx.dred, dth0, dcn0);
+        mv_sum2(dth0, dcn0, sm_nx.dred);
+        dth0 += s_down[s_sel ? 2 : 0];                     // the updated rows' part
+        dcn0 += s_down[s_sel ? 3 : 1];
+        const double ratio = dth0 + dcn0 + pend.logq;
+        pend_acc = pend.valid && pend.logu < ratio;        // NaN -> reject
     }
-    if (role == 1) {
-        // ------------------------------------------------------------ speculative E->I-type proposal
-        const Move *fix = (pend_acc && pendp->tgt == next.tgt) ? pendp : nullptr;
-        mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
-        mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
-        if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
-        // ... and its log-ratio over the rows it updates (k_move_delta then does the band only); the F band
-        // of an accepted pending update is not in F yet and is added on the fly
+    if (role != 0) {
+        // ------------------------------------------------------------ speculative proposal (role 1: E->I-type
+        // of this pair, role 2: S->E-type of the next pair)
+        const Move *fix = (pend_acc && pendp->tgt == mine.tgt) ? pendp : nullptr;
+        RSTAMP(9);
+        mv_rows_to_lds(d, w, s, b, mine, pre_ok, pre_nx, fix, L, rtl);
+        mv_propose(d, w, s, ch, b, mine, sm_nx, L, ltab);
+        RSTAMP(10);
+        Move *out = (role == 1 ? ch.mv : ch.mvs) + (size_t)(pbuf ^ 1) * s.B + b;
+        move_copy(out, &sm_nx.mv, MVB - WAVE);             // by the last wave: nobody's loads queue behind the store
+        // ... and its log-ratio over the rows it updates (for role 1, k_move_delta then does the band only); the F
+        // band of an accepted pending update is not in F yet and is added on the fly
         const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
-        mv_own_rows_to_down(d, c, w, s, ch, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred, pbuf ^ 1, 0);
+        double *od = role == 1 ? ch.Down + (((size_t)(pbuf ^ 1) * 2 + 0) * s.B + b) * 2
+                               : ch.DownS + ((size_t)(pbuf ^ 1) * s.B + b) * 2;
+        mv_own_rows_to_down(d, c, w, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred, od);
+        RSTAMP(11);
         return;
     }
     if (!have_prev && tid == 64) ch.fpend[b].valid = 0;    // first launch of a sweep: nothing pending
-    // before the first store role 1 could mistake for the state at entry: has it fetched its totals?
-    // (bounded wait; normally role 1 is long past that point when the accept test above is done)
-    bool late = false;
-    auto wait_role1 = [&]() {
+    // before the first store a speculative role could mistake for the state at entry: has it fetched its totals?
+    // (bounded wait; normally the roles are long past that point when the accept test above is done)
+    bool late = false, late2 = false;
+    auto wait_roles = [&]() {
         if (tid == 0) {
             int spins = 0;
-            while (__hip_atomic_load(ch.hand + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token && spins < 4000) {
-                __builtin_amdgcn_s_sleep(2);
-                ++spins;
+            if (do_nx) {
+                while (__hip_atomic_load(ch.hand + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token && spins < 4000) {
+                    __builtin_amdgcn_s_sleep(2);
+                    ++spins;
+                }
             }
             s_late = spins >= 4000 ? 1 : 0;
-            if (spins >= 4000) ch.late[b] += 1;                // visible through seir_sampler_pair_timeouts
-            // relaxed polls, one acquire once the token is seen: this workgroup's stores below are ordered after it
+            int spins2 = 0;
+            if (do_pre) {
+                while (__hip_atomic_load(ch.hand2 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token && spins2 < 4000) {
+                    __builtin_amdgcn_s_sleep(2);
+                    ++spins2;
+                }
+            }
+            s_late2 = spins2 >= 4000 ? 1 : 0;
+            if (spins >= 4000 || spins2 >= 4000) ch.late[b] += 1;   // visible through seir_sampler_pair_timeouts
+            // relaxed polls, one acquire once the tokens are seen: this workgroup's stores below are ordered after it
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         lds_barrier();
         late = s_late != 0;
+        late2 = s_late2 != 0;
     };
-    bool waited = !do_nx;                                  // no role 1 in this launch: nothing to wait for
+    bool waited = !do_nx && !do_pre;                       // no speculative role in this launch: nothing to wait for
     if (have_prev) {
         const Move &mv = *pendp;
-        if (pend_acc && !waited) { wait_role1(); waited = true; }
-        // The F band of an accepted E->I update is NOT written here: k_move_delta (or k_apply_fpend at the
-        // end of the sweep) does it with the whole chip; the S->E update below adds the pending band to
+        if (pend_acc && !waited) { wait_roles(); waited = true; }
+        // The F band of an accepted E->I update is NOT written here: k_move_delta (or k_record / k_apply_fpend
+        // at the end of the sweep) does it with the whole chip; the S->E update below adds the pending band to
         // the F values it reads.
-        if (tid == 64) {
-            Move *fp = ch.fpend + b;
-            if (pend_acc && mv.any_dI) { *fp = mv; fp->valid = 1; }
-            else fp->valid = 0;
-        }
+        if (pend_acc && mv.any_dI) move_copy(ch.fpend + b, &mv, MVB - WAVE);     // mv.valid == 1: it was accepted
+        else if (tid == MVB - WAVE) ch.fpend[b].valid = 0;
         if (pend_acc) mv_apply_rows(d, w, s, b, mv);
         if (tid == 0) {
             if (pend_acc) {
@@ -911,24 +951,52 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     // ---- (2) the whole S->E-type update
     bool se_acc = false;
     if (do_se) {
-        // the pending update was of the other plane (tgt 1): nothing to correct in plane 0's totals
-        mv_rows_to_lds(d, w, s, b, se, pre_ok, pre_se, nullptr, L, rtl);
-        PSTAMP(2);
-        mv_propose(d, w, s, ch, b, se, sm_se, L, ltab);
-        PSTAMP(3);
-        const Move &mv = sm_se.mv;
-        double dth = 0.0, dcn = 0.0;
         const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
-        if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, M, ltab, dth, dcn, fpp);
-        PSTAMP(4);
-        mv_sum2(dth, dcn, sm_se.dred);
+        // the pre-drawn proposal stands unless the previous launch ruled it out or one of its rows was changed
+        // by the E->I-type update accepted there (note.rows) or by the one just finalized
+        if (tid == 0) {
+            int use = pre_avail && note.ok;
+            if (use) {
+                const Move &mv = sm_se.mv;
+                for (int i = 0; i < mv.n; ++i) {
+                    for (int j = 0; j < note.n; ++j) use &= mv.m[i] != note.rows[j];
+                    if (pend_acc)
+                        for (int j = 0; j < pendp->n; ++j) use &= mv.m[i] != pendp->m[j];
+                }
+                // an out-of-range sub-move leaves no row in mv.m: its rows cannot be checked -- it is rejected
+                // whatever the state is, so the proposal stands (mv.valid == 0)
+            }
+            s_use_pre = use;
+        }
+        lds_barrier();
+        const bool use_pre = s_use_pre != 0;
+        double dth = 0.0, dcn = 0.0;
+        if (!use_pre) {
+            if (pre_avail) {                                // not drawn at entry: draw the uniforms and the header now
+                lds_barrier();
+                mv_draw(s, ch, b, se, sm_se, T);
+            }
+            // the pending update was of the other plane (tgt 1): nothing to correct in plane 0's totals
+            mv_rows_to_lds(d, w, s, b, se, pre_ok, pre_se, nullptr, L, rtl);
+            PSTAMP(2);
+            mv_propose(d, w, s, ch, b, se, sm_se, L, ltab);
+            PSTAMP(3);
+        }
+        const Move &mv = sm_se.mv;
+        if (use_pre && fpp == nullptr) {
+            dth = pre_down[0]; dcn = pre_down[1];           // F under the proposal's rows is what role 2 saw
+        } else {
+            if (mv.valid && mv.n > 0) own_rows_delta<MVB>(d, c, w, b, mv, psi, 0, M, ltab, dth, dcn, fpp);
+            PSTAMP(4);
+            mv_sum2(dth, dcn, sm_se.dred);
+        }
         if (tid == 0) {
             const double ratio = dth + dcn + mv.logq;
             s_acc_se = (mv.valid && mv.logu < ratio) ? 1 : 0;    // NaN -> reject
         }
         lds_barrier();
         se_acc = s_acc_se != 0;
-        if (se_acc && !waited) { wait_role1(); waited = true; }
+        if (se_acc && !waited) { wait_roles(); waited = true; }
         if (se_acc) mv_apply_rows(d, w, s, b, mv);
         if (tid == 0) {
             if (se_acc) {
@@ -969,11 +1037,23 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         lds_barrier();
         if (s_conf) {                                        // rare: draw it again from the final state
             mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
-            if (tid == 0) ch.mvfix[(size_t)(pbuf ^ 1) * s.B + b] = sm_nx.mv;
+            move_copy(ch.mvfix + (size_t)(pbuf ^ 1) * s.B + b, &sm_nx.mv, MVB - WAVE);
             const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
-            mv_own_rows_to_down(d, c, w, s, ch, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred, pbuf ^ 1, 1);
+            mv_own_rows_to_down(d, c, w, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred,
+                                ch.Down + (((size_t)(pbuf ^ 1) * 2 + 1) * s.B + b) * 2);
         }
         PSTAMP(7);
+    }
+    // ---- (4) the note for the next launch about the proposal role 2 is pre-drawing
+    if (do_pre && tid == 0) {
+        PairNote nt;
+        // if the wait never happened nothing was written in this launch, and a late role 2 read the final state
+        nt.ok = (!se_acc && !(waited && late2)) ? 1 : 0;
+        nt.n = 0;
+        for (int j = 0; j < MMAX; ++j) nt.rows[j] = -1;
+        if (pend_acc)
+            for (int j = 0; j < pendp->n; ++j) nt.rows[nt.n++] = pendp->m[j];
+        ch.prev[(size_t)(pbuf ^ 1) * s.B + b] = nt;
     }
 }
 

@@ -63,8 +63,19 @@ struct Move {
     double logq, logu;
 };
 
+// A descriptor is 60 dwords: copied by one dword per lane of the wave that starts at thread t0 -- one
+// coalesced wave instruction instead of 60 dependent ones from a single lane (whose later loads would
+// also queue behind them: vmcnt counts in issue order)
+constexpr int MOVE_DW = (int)(sizeof(Move) / 4);
+static_assert(sizeof(Move) % 4 == 0 && MOVE_DW <= 64, "Move must fit one dword per lane of a wave");
+__device__ __forceinline__ void move_copy(Move *dst, const Move *src, int t0) {
+    const int i = (int)threadIdx.x - t0;
+    if (i >= 0 && i < MOVE_DW) reinterpret_cast<int *>(dst)[i] = reinterpret_cast<const int *>(src)[i];
+}
+
 constexpr int NMVTR = 2 + 4 * MMAX;   // is_accepted, target_log_prob, m[], t[], delta_t[], x_star[]
 
+struct PairNote;
 struct Chains {
     double *q, *p, *q0, *grad, *var, *rv_mean, *rv_m2;   // [B][Pp]
     double *hs;                                          // [B][NHS]
@@ -72,7 +83,11 @@ struct Chains {
     Move *fpend;                                         // [B] accepted E->I-type update whose F band is still to be applied (valid = 1)
     Move *mvfix;                                         // [2][B] E->I-type proposal re-drawn after a row conflict (k_move_pair)
     unsigned *hand;                                      // [B] k_move_pair: token of the launch whose role 1 has its totals
-    unsigned *late;                                      // [B] k_move_pair: launches whose role 0 gave up waiting for role 1
+    unsigned *late;                                      // [B] k_move_pair: launches whose role 0 gave up waiting for a speculative role
+    unsigned *hand2;                                     // [B] the same token for role 2 (pre-drawn S->E-type proposal)
+    Move *mvs;                                           // [2][B] S->E-type proposal pre-drawn for the next launch (k_move_pair, role 2)
+    double *DownS;                                       // [2][B][2] its own-rows log-ratio {theta, const}
+    struct PairNote *prev;                               // [2][B] role 0's note about the proposal being pre-drawn
     int *mvsel;                                          // [2][B] 1: the pending descriptor is mvfix, 0: mv[buf]
     double *Dpart;                                       // [B][nrb_d][2]
     double *Down;                                        // [2][2][B][2] paired form: own-rows log-ratio of the speculative /
@@ -1006,11 +1021,16 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
                                                double &dcn, const Move *fp = nullptr) {
     const double r_ei = d.nu * d.dt, L_ei = d.L_ei;
     const double *ea = w.ea + (size_t)b * d.Tp;
-    for (int i0 = 0; i0 < mv.n; ++i0) {
+    // the (updated row, day of the hull) pairs are spread over the threads: the rows of a proposal are
+    // independent latency chains (loads, then a few hundred dependent fp64 operations per cell), so they
+    // run side by side instead of one after the other
+    const int span = mv.HI - mv.LO + 1;
+    const int total = span > 0 ? mv.n * span : 0;
+    for (int idx = (int)threadIdx.x; idx < total; idx += NT) {
+        const int i0 = idx / span, t = mv.LO + (idx - i0 * span);
         const int j = mv.m[i0];
-        if (j < r_lo || j >= r_hi) continue;     // block-uniform
+        if (j < r_lo || j >= r_hi) continue;
         const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
-        const double eb = w.eb[(size_t)b * d.Mp + j];
         double coef[MMAX];
 #pragma unroll
         for (int i = 0; i < MMAX; ++i)
@@ -1022,7 +1042,7 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
         for (int i = 0; i < MMAX; ++i)
             cfp[i] = (fp && i < fp->n) ? c.Cstar[(size_t)fp->m[i] * d.Kp0 + j] * c.invN[fp->m[i]] * (double)(-fp->dsrc[i])
                                        : 0.0;
-        for (int t = mv.LO + (int)threadIdx.x; t <= mv.HI; t += NT) {
+        {
             double dF = 0.0;
 #pragma unroll
             for (int i = 0; i < MMAX; ++i)
@@ -1039,11 +1059,14 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
             const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
             const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
             const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
+            const double eb = w.eb[(size_t)b * d.Mp + j];
             double F = w.F[rowoff + t];
-            if (fp) {
+            if (fp) {                                  // summed first, as apply_f_band does: F + (c0 + c1) is then
+                double dFp = 0.0;                      // bit for bit the value the band will leave in memory
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)
-                    if (i < fp->n && t > fp->lo[i] && t <= fp->hi[i]) F += cfp[i];
+                    if (i < fp->n && t > fp->lo[i] && t <= fp->hi[i]) dFp += cfp[i];
+                if (dFp != 0.0) F += dFp;
             }
             const double ee = ea[t] * eb, psiW = psi * c.W[t];
             // only the terms the update changes (terms(new) - terms(old) with the rest cancelled):
@@ -1179,10 +1202,10 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
 #define DSTAMP(i) do {} while (0)
 #endif
     DSTAMP(0);
-    if (threadIdx.x == 0) mvA = ch.mv[(size_t)buf * s.B + b];
-    if (threadIdx.x == 64) mvB = ch.mvfix[(size_t)buf * s.B + b];
-    if (threadIdx.x == 65) mv_sel = ch.mvsel[(size_t)buf * s.B + b];
-    if (apply_f && threadIdx.x == 128) fp = ch.fpend[b];
+    move_copy(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
+    move_copy(&mvB, ch.mvfix + (size_t)buf * s.B + b, 64);
+    if (threadIdx.x == 192) mv_sel = ch.mvsel[(size_t)buf * s.B + b];
+    if (apply_f) move_copy(&fp, ch.fpend + b, 128);
     log_table_to_lds(ltab, c.logtab);              // includes the barrier that publishes the descriptors
     const Move &mv = mv_sel ? mvB : mvA;           // see load_pending() in moves_kernel.h
     if (apply_f && fp.valid == 1) {

@@ -684,7 +684,8 @@ struct seir_sampler {
     bool use_graph = false;       // seir_sampler_desc::use_graph
     bool hmc_chunked = true;      // hmc_mode 1: every leapfrog step by the single-workgroup kernel
     int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
-    int moves_mode = 0;           // 0 = paired launches (k_move_pair); 1 = one proposal kernel per update (k_move_pa2)
+    int moves_mode = 0;           // 0 = paired launches (k_move_pair) with the S->E-type proposal pre-drawn one launch ahead;
+                                  // 1 = one proposal kernel per update (k_move_pa2); 2 = paired launches without the pre-draw
     int graph_skew = 0, graph_aff = 3;   // context options the captured graph was built with
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
@@ -738,8 +739,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         return fail(SEIR_ERR_INVALID, "occult t_range [%d,%d) outside [0,%d)", ds->t_range_lo, ds->t_range_hi, d.T);
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
-    if (ds->moves_mode < 0 || ds->moves_mode > 1 || ds->hmc_mode < 0 || ds->hmc_mode > 1)
-        return fail(SEIR_ERR_INVALID, "moves_mode and hmc_mode are 0 or 1");
+    if (ds->moves_mode < 0 || ds->moves_mode > 2 || ds->hmc_mode < 0 || ds->hmc_mode > 1)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..2, hmc_mode 0 or 1");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
@@ -798,6 +799,10 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.mvsel, (size_t)2 * B);
     S_ALLOC(ch.hand, (size_t)B);
     S_ALLOC(ch.late, (size_t)B);
+    S_ALLOC(ch.hand2, (size_t)B);
+    S_ALLOC(ch.mvs, (size_t)2 * B);
+    S_ALLOC(ch.DownS, (size_t)2 * B * 2);
+    S_ALLOC(ch.prev, (size_t)2 * B);
     S_ALLOC(ch.Dpart, (size_t)B * c.nrb_d * 2);
     S_ALLOC(ch.Down, (size_t)2 * 2 * B * 2);
     S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
@@ -1094,23 +1099,31 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
         int have_prev = 0, pbuf = 0;
-        if (s->moves_mode == 0 && c.n_scans > 30) s->moves_mode = 1;   // k_move_pair's launch tokens cover 62 launches per sweep
-        if (s->moves_mode == 0) {
+        if (s->moves_mode != 1 && c.n_scans > 30) s->moves_mode = 1;   // k_move_pair's launch tokens cover 62 launches per sweep
+        if (s->moves_mode != 1) {
             // paired form: [finalize pending E->I-type | whole S->E-type update | propose E->I-type], then
             // the log-ratio of the E->I-type proposal over its band: 4 launches per scan
+            const int npairs = 2 * c.n_scans;
+            int have_pre = 0;
             for (int scan = 0; scan < c.n_scans; ++scan)
                 for (int half = 0; half < 2; ++half) {
+                    const int pair = 2 * scan + half;
                     const MoveSpec se{half, 0, 2 * half, scan}, nx{half, 1, 2 * half + 1, scan};
-                    hipLaunchKernelGGL(k_move_pair, dim3(2 * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, se, nx,
-                                       have_prev, pbuf, nb, 2 * scan + half, s->pair_debug);
+                    // a third role pre-draws the S->E-type proposal of the next pair (same sweep)
+                    const bool pre = s->moves_mode == 0 && pair + 1 < npairs;
+                    const int nh = (half + 1) & 1, nscan = scan + (half == 1 ? 1 : 0);
+                    const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : MoveSpec{-1, 0, 0, 0};
+                    hipLaunchKernelGGL(k_move_pair, dim3((pre ? 3 : 2) * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch,
+                                       se, nx, se_next, have_prev, have_pre, pbuf, nb, pair, s->pair_debug);
+                    have_pre = pre ? 1 : 0;
                     pbuf ^= 1;
                     hipLaunchKernelGGL((k_move_delta<false>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
                 }
             if (have_prev) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
-                hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, 1,
-                                   pbuf, nb, 62, 0);
+                hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, none, 1,
+                                   0, pbuf, nb, 62, 0);
                 // the F band of the last accepted E->I update: by k_record's waves when it runs anyway
                 if (s->record_events) fpend_in_record = 1;
                 else hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);

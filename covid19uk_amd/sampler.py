@@ -40,7 +40,8 @@ class ChainSampler:
         occult_nmax, num_event_time_updates (mcmc_kernel_factory.py:79-81,106,123).
 
         Launch form (seir_sampler_desc, ABI v2; none of it changes what is sampled):
-        `moves` "paired" (k_move_pair, default) | "split" (one proposal kernel per update, cross-check);
+        `moves` "paired" (k_move_pair with pre-drawn S->E-type proposals, default) | "paired-nopre" |
+        "split" (one proposal kernel per update, cross-check);
         `hmc` "chunk" (default) | "single"; `use_graph`; `chain_groups`.
         `disable`: sub-kernels that draw their proposal but always reject, any of
         "hmc", "move/S->E", "move/E->I", "occult/S->E", "occult/E->I" (invariant-distribution tests)."""
@@ -65,7 +66,7 @@ class ChainSampler:
             num_leapfrog_steps=int(num_leapfrog_steps), trace_capacity=self.cap,
             first_chain_id=int(first_chain_id), record_events=int(self.record_events),
             seed=int(seed) & (2 ** 64 - 1),
-            moves_mode={"paired": 0, "split": 1}[moves], hmc_mode={"chunk": 0, "single": 1}[hmc],
+            moves_mode={"paired": 0, "split": 1, "paired-nopre": 2}[moves], hmc_mode={"chunk": 0, "single": 1}[hmc],
             use_graph=int(bool(use_graph)), chain_groups=int(chain_groups), disable_mask=mask,
             debug_pair=int(debug_pair))
         self._s = ctypes.c_void_p()

@@ -169,8 +169,10 @@ typedef struct {
     int32_t record_events;          /* 1: record samples/seir for every draw */
     uint64_t seed;
     /* ---- ABI v2: launch form and test hooks; all-zero = the defaults ---------------------------- */
-    int32_t moves_mode;             /* 0: paired event-update launches (k_move_pair); 1: one proposal kernel
-                                       per update (k_move_pa2) -- kept as a cross-check, same draws */
+    int32_t moves_mode;             /* 0: paired event-update launches (k_move_pair) with the S->E-type proposal
+                                       pre-drawn one launch ahead; 1: one proposal kernel per update (k_move_pa2)
+                                       -- kept as a cross-check; 2: paired launches without the pre-draw.
+                                       Same draws in all three */
     int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks (k_hmc_chunk); 1: every step
                                        by the single-workgroup kernel -- same draws up to summation order */
     int32_t use_graph;              /* 1: replay the sweep as a captured hipGraph (default: stream launches) */

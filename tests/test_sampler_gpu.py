@@ -55,7 +55,7 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
             assert np.max(np.abs(trace.theta[i, b] - o["theta"]) / scale) < theta_rtol, (i, b, "theta")
 
 
-@pytest.mark.parametrize("moves", ["paired", "split", "paired+single"])
+@pytest.mark.parametrize("moves", ["paired", "split", "paired-nopre", "paired+single"])
 @pytest.mark.parametrize("name,cfg,seed,eps,n", [
     ("micro_5x24", CFG_SMALL, 1, 0.002, 12),
     ("ni11", CFG_REF, 2, 0.002, 8),
@@ -67,8 +67,9 @@ def _compare(trace, oracles, n, B, cfg, theta_rtol=1e-6, lp_rtol=1e-9):
     ("micro_65x65", CFG_SMALL, 7, 0.0001, 3),
 ])
 def test_fixed_kernel_sweeps_match_oracle(api, name, cfg, seed, eps, n, moves):
-    """Both forms of the event-update launches -- paired (k_move_pair, default) and one proposal
-    kernel per update (k_move_pa2, the cross-check) -- against the oracle."""
+    """The forms of the event-update launches -- paired with the S->E-type proposal pre-drawn one launch
+    ahead (k_move_pair, default), paired without the pre-draw, and one proposal kernel per update
+    (k_move_pa2, the cross-check) -- against the oracle."""
     # "+single": every leapfrog step by the single-workgroup kernel instead of the 64-lane chunks
     form = dict(moves=moves.split("+")[0], hmc="single" if moves.endswith("+single") else "chunk")
     SeirModel, ChainSampler = api
@@ -223,11 +224,12 @@ def test_running_log_prob_matches_full_reevaluation_syn2048(api):
         assert np.array_equal(tr.events[-1, b], ev1[b].astype(np.int32))
 
 
-@pytest.mark.parametrize("hook", ["1", "2"])
+@pytest.mark.parametrize("hook", ["1", "2", "4", "8", "10"])
 def test_pair_kernel_handshake_paths(api, hook):
-    """k_move_pair's role 0 waits for role 1's token before its first store (hook 1: the token comes
-    late) and re-draws the E->I proposal itself when role 1 never shows up (hook 2): same traces.
-    The time-outs of hook 2 are counted (seir_sampler_pair_timeouts); an undisturbed run has none."""
+    """k_move_pair's role 0 waits for the speculative roles' tokens before its first store (hooks 1 / 4:
+    the token of role 1 / role 2 comes late) and discards their output when they never show up (hooks
+    2 / 8; 10 = both): same traces.  The time-outs are counted (seir_sampler_pair_timeouts); an
+    undisturbed run has none."""
     SeirModel, ChainSampler = api
     case = H.build_case("micro_5x24", 1, alpha_t_sd=0.005)
     B, n = 2, 6
@@ -249,7 +251,7 @@ def test_pair_kernel_handshake_paths(api, hook):
             s.sample(n)
             assert not s.pair_timeouts().any()
     _compare(tr, oracles, n, B, CFG_SMALL)
-    assert (late > 0).all() if hook == "2" else not late.any()
+    assert (late > 0).all() if int(hook) & 10 else not late.any()
 
 
 @pytest.mark.parametrize("name,B,n,eps", [("uk380", 8, 40, 1.5e-5), ("micro_17x70", 5, 40, 0.0004)])
@@ -278,7 +280,7 @@ def test_repeated_runs_are_bitwise_identical(api, name, B, n, eps):
                 assert np.array_equal(a, b_), rep
 
 
-@pytest.mark.parametrize("forms", ["chunk,paired", "single,split"])
+@pytest.mark.parametrize("forms", ["chunk,paired", "single,split", "chunk,paired-nopre"])
 @pytest.mark.parametrize("name,B,n,eps", [("uk380", 8, 25, 1.5e-5), ("micro_17x70", 5, 25, 0.0004), ("ni11", 2, 25, 0.002)])
 def test_results_do_not_depend_on_workgroup_timing(api, name, B, n, eps, forms):
     """The debug-skew option delays a pseudo-random third of the workgroups of every launch by ~30 us -- longer
@@ -317,18 +319,26 @@ def test_paired_and_split_agree_over_many_sweeps_with_frequent_conflicts(api, na
     B, n = 4, 300
     u, ev = _start(case, B, 41)
     out = {}
-    for mode in ("paired", "split"):
+    for mode in ("paired", "split", "paired-nopre"):
         with SeirModel(case["cov"], case["init"], max_chains=B) as model:
             with ChainSampler(model, cfg, B, seed=5, trace_capacity=n, moves=mode) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=eps)
                 out[mode] = s.sample(n)
-    a, b_ = out["paired"], out["split"]
-    assert np.array_equal(a.events, b_.events)
+                assert not s.pair_timeouts().any()
+    a = out["paired"]
+    for other in ("split", "paired-nopre"):
+        b_ = out[other]
+        assert np.array_equal(a.events, b_.events), other
+        for key in a.moves:
+            assert np.array_equal(a.moves[key]["proposed_delta"], b_.moves[key]["proposed_delta"]), (other, key)
+            assert np.array_equal(a.moves[key]["is_accepted"], b_.moves[key]["is_accepted"]), (other, key)
+        assert np.array_equal(a.hmc["is_accepted"], b_.hmc["is_accepted"]), other
+    # with and without the pre-draw the same arithmetic runs: every continuous quantity bit for bit
+    c_ = out["paired-nopre"]
+    assert np.array_equal(a.theta, c_.theta)
     for key in a.moves:
-        assert np.array_equal(a.moves[key]["proposed_delta"], b_.moves[key]["proposed_delta"]), key
-        assert np.array_equal(a.moves[key]["is_accepted"], b_.moves[key]["is_accepted"]), key
-    assert np.array_equal(a.hmc["is_accepted"], b_.hmc["is_accepted"])
+        assert np.array_equal(a.moves[key]["target_log_prob"], c_.moves[key]["target_log_prob"]), key
     assert sum(int(a.moves[k]["is_accepted"].sum()) for k in a.moves) > 200
 
 
@@ -341,12 +351,16 @@ def test_paired_and_split_launch_forms_agree_at_uk380(api):
     B, n = 4, 40
     u, ev = _start(case, B, 12, scale=0.002)
     out = {}
-    for mode in ("paired", "split"):
+    for mode in ("paired", "split", "paired-nopre"):
         with SeirModel(case["cov"], case["init"], max_chains=B) as model:
             with ChainSampler(model, CFG_REF, B, seed=21, trace_capacity=n, moves=mode) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=1.5e-5)
                 out[mode] = s.sample(n)
+    a, c_ = out["paired"], out["paired-nopre"]
+    assert np.array_equal(a.events, c_.events) and np.array_equal(a.theta, c_.theta)
+    for key in a.moves:
+        assert np.array_equal(a.moves[key]["target_log_prob"], c_.moves[key]["target_log_prob"]), key
     a, b_ = out["paired"], out["split"]
     assert np.array_equal(a.events, b_.events)
     for key in a.moves:

@@ -1,7 +1,7 @@
 import ctypes, os, sys, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from covid19uk_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libseirhip_stamps" + os.environ.get("STAMP_SLOT", "") + ".so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libseirhip_stamps" + os.environ.get("STAMP_SLOT", "") + ("r2" if os.environ.get("STAMP_ROLE") == "2" else "") + ".so")
 from covid19uk_amd import synth
 from covid19uk_amd.sampler import ChainSampler
 from covid19uk_amd.seir import SeirModel
@@ -31,6 +31,8 @@ with SeirModel(cov, init, max_chains=B) as model:
             print("k_move_pair block 0 (se slot", int(os.environ.get("STAMP_SLOT", "1")) & 2, "): entry+finalize", (st[1]-st[0])*10, "se tables", (st[2]-st[1])*10,
                   "se propose", (st[3]-st[2])*10, "se delta", (st[4]-st[3])*10, "se accept/apply/trace", (st[5]-st[4])*10,
                   "nx tables", (st[6]-st[5])*10, "nx propose+store", (st[7]-st[6])*10, "ns; total", (st[7]-st[0])*10)
+            print("   speculative role", os.environ.get("STAMP_ROLE", "1"), ": entry+pending", (st[9]-st[8])*10, "tables+propose", (st[10]-st[9])*10,
+                  "store+own-rows", (st[11]-st[10])*10, "ns; total", (st[11]-st[8])*10)
             print("k_move_delta block", os.environ.get("STAMP_BLOCK", "0"), ": mv+ltab", (st[13]-st[12])*10, "band", (st[14]-st[13])*10,
                   "own rows", (st[15]-st[14])*10, "ns")
         tr = s.read_trace(3, events=False)
