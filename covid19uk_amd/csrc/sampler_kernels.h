@@ -1335,6 +1335,10 @@ __global__ __launch_bounds__(256) void k_range_totals(Dims d, Work w, SamplerCfg
     }
 }
 
+// slot0 = sweep counter of chain 0 minus `first`: the next sweep is recorded in trace slot `first`
+// (unsigned arithmetic: slot = sweep - slot0 stays right across the wrap)
+__global__ void k_set_slot0(Chains ch, unsigned first) { ch.slot0[0] = ch.sweep[0] - first; }
+
 __global__ void k_advance(Chains ch, int b0, int nb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nb) ch.sweep[b0 + i] += 1;

@@ -681,6 +681,9 @@ struct seir_sampler {
     std::vector<hipGraphExec_t> gexec;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
+    hipStream_t copy_stream = nullptr;    // overlapped egress (seir_sampler_read_trace_async)
+    hipEvent_t ev_burst = nullptr, ev_copy = nullptr;
+    bool copy_pending = false;
     bool use_graph = false;       // seir_sampler_desc::use_graph
     bool hmc_chunked = true;      // hmc_mode 1: every leapfrog step by the single-workgroup kernel
     int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
@@ -715,6 +718,9 @@ extern "C" void seir_sampler_destroy(seir_sampler *s) {
     for (auto st : s->gstream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto e : s->ev_join) if (e) (void)hipEventDestroy(e);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
+    if (s->ev_burst) (void)hipEventDestroy(s->ev_burst);
+    if (s->ev_copy) (void)hipEventDestroy(s->ev_copy);
     for (void *p : s->allocs) (void)hipFree(p);
     Work &w = s->ctx->w;
     for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
@@ -821,6 +827,9 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     }
     if (!rc) {
         hipError_t e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_burst, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_copy, hipEventDisableTiming);
         for (int g = 0; g < s->ngroups && e == hipSuccess; ++g) {
             e = hipStreamCreateWithFlags(&s->gstream[g], hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join[g], hipEventDisableTiming);
@@ -1002,6 +1011,16 @@ extern "C" int seir_sampler_reset_trace(seir_sampler *s) {
     if (rc) return rc;
     // slot0 = sweep counter of chain 0 (all chains advance together)
     HIP_TRY(hipMemcpyAsync(s->ch.slot0, s->ch.sweep, sizeof(unsigned), hipMemcpyDeviceToDevice, s->ctx->stream));
+    return 0;
+}
+
+extern "C" int seir_sampler_reset_trace_at(seir_sampler *s, int32_t first_slot) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (first_slot < 0 || first_slot >= s->cfg.cap)
+        return fail(SEIR_ERR_INVALID, "first_slot %d outside [0, %d)", first_slot, s->cfg.cap);
+    hipLaunchKernelGGL(k_set_slot0, dim3(1), dim3(1), 0, s->ctx->stream, s->ch, (unsigned)first_slot);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1214,6 +1233,58 @@ extern "C" int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t c
         HIP_TRY(hipMemcpyAsync(moves, s->ch.tr_mv + (size_t)first * B * 4 * NMVTR,
                                sizeof(double) * count * B * 4 * NMVTR, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int seir_sampler_read_trace_async(seir_sampler *s, int32_t first, int32_t count, double *theta,
+                                             int32_t *events, double *hmc, double *moves) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    const Dims &d = s->ctx->d;
+    const SamplerCfg &c = s->cfg;
+    if (first < 0 || count < 0 || first + count > c.cap)
+        return fail(SEIR_ERR_INVALID, "trace range [%d,%d) outside capacity %d", first, first + count, c.cap);
+    if (events && !s->record_events) return fail(SEIR_ERR_STATE, "sampler was created with record_events=0");
+    // the copies start when everything queued on the context stream so far (the burst) is done; what is
+    // queued there afterwards overlaps them
+    HIP_TRY(hipEventRecord(s->ev_burst, s->ctx->stream));
+    hipStream_t st = s->copy_stream;
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_burst, 0));
+    const size_t B = c.B;
+    if (theta)
+        HIP_TRY(hipMemcpyAsync(theta, s->ch.tr_theta + (size_t)first * B * d.P, sizeof(double) * count * B * d.P,
+                               hipMemcpyDeviceToHost, st));
+    if (events)
+        HIP_TRY(hipMemcpyAsync(events, s->ch.tr_events + (size_t)first * B * d.M * d.T * 3,
+                               sizeof(int32_t) * count * B * d.M * d.T * 3, hipMemcpyDeviceToHost, st));
+    if (hmc)
+        HIP_TRY(hipMemcpyAsync(hmc, s->ch.tr_hmc + (size_t)first * B * 3, sizeof(double) * count * B * 3,
+                               hipMemcpyDeviceToHost, st));
+    if (moves)
+        HIP_TRY(hipMemcpyAsync(moves, s->ch.tr_mv + (size_t)first * B * 4 * NMVTR,
+                               sizeof(double) * count * B * 4 * NMVTR, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(s->ev_copy, st));
+    s->copy_pending = true;
+    return 0;
+}
+
+extern "C" int seir_sampler_trace_wait(seir_sampler *s) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (s->copy_pending) {
+        HIP_TRY(hipEventSynchronize(s->ev_copy));
+        s->copy_pending = false;
+    }
+    return 0;
+}
+
+extern "C" int seir_host_alloc(void **p, uint64_t bytes) {
+    if (!p) return fail(SEIR_ERR_INVALID, "null pointer");
+    HIP_TRY(hipHostMalloc(p, bytes ? bytes : 8, hipHostMallocDefault));
+    return 0;
+}
+extern "C" int seir_host_free(void *p) {
+    HIP_TRY(hipHostFree(p));
     return 0;
 }
 

@@ -229,9 +229,17 @@ def run_mcmc(sampler: ChainSampler, config, posteriors, log=sys.stderr):
     sampler.set_kernel(step_size=step_size, variance=sampler.get_kernel()[1])
     nb, ns = int(config["num_bursts"]), int(config["num_burst_samples"])
     t0 = time.perf_counter()
-    for i in range(nb):
-        flush(sampler.sample(ns))
-        print(f"  burst {i + 1}/{nb}", file=log, flush=True)
+    if nb and ns and sampler.cap >= 2 * ns:
+        # bursts overlap: while burst k+1 runs, burst k crosses PCIe into page-locked memory and is written
+        # to the HDF5 file on a worker thread (ChainSampler.sample_bursts)
+        def on_burst(tr, i):
+            flush(tr)
+            print(f"  burst {i + 1}/{nb}", file=log, flush=True)
+        sampler.sample_bursts(nb, ns, on_burst)
+    else:
+        for i in range(nb):
+            flush(sampler.sample(ns))
+            print(f"  burst {i + 1}/{nb}", file=log, flush=True)
     dt = time.perf_counter() - t0
     if nb * ns:
         print(f"Sampling: {nb * ns * sampler.B / dt:.1f} posterior samples/s "
@@ -254,7 +262,7 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=0):
     P = model_spec.num_params(M, T)
     cfg = event_kernel_config(config)
     num_samples = warmup_size() + int(config["num_burst_samples"]) * int(config["num_bursts"])
-    cap = max(800, int(config["num_burst_samples"]))
+    cap = max(800, 2 * int(config["num_burst_samples"]))      # two halves: a burst runs while the previous one is written
 
     model = SeirModel(cov, initial_state, max_chains=B, device=device)
     sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),

@@ -30,6 +30,41 @@ class Trace:
     moves: dict              # MOVE_KEYS -> dict(is_accepted [n,B], target_log_prob [n,B], proposed_delta [n,B,4,m])
 
 
+class PinnedTrace:
+    """Page-locked host arrays for `count` sweeps of the burst buffer (seir_host_alloc): the target of
+    `ChainSampler.read_trace_async`.  Views are valid until close()."""
+
+    def __init__(self, sampler: "ChainSampler", count: int, events: bool = True):
+        self._lib = sampler._lib
+        self.count = int(count)
+        B, P, M, T = sampler.B, sampler.P, sampler.M, sampler.T
+        self._ptrs = []
+        self.theta = self._alloc((count, B, P), np.float64)
+        self.events = self._alloc((count, B, M, T, 3), np.int32) if (events and sampler.record_events) else None
+        self.hmc = self._alloc((count, B, 3), np.float64)
+        self.moves = self._alloc((count, B, 4, _lib.MOVE_TRACE), np.float64)
+
+    def _alloc(self, shape, dtype):
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        _lib.check(self._lib.seir_host_alloc(ctypes.byref(p), max(nbytes, 8)))
+        self._ptrs.append(p)
+        buf = (ctypes.c_char * max(nbytes, 8)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+    def close(self):
+        self.theta = self.events = self.hmc = self.moves = None
+        for p in self._ptrs:
+            self._lib.seir_host_free(p)
+        self._ptrs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ChainSampler:
     def __init__(self, model: SeirModel, config: dict, num_chains: int, seed: int = 0,
                  t_range=None, num_leapfrog_steps: int = 16, trace_capacity: int = 100,
@@ -73,6 +108,9 @@ class ChainSampler:
         _lib.check(self._lib.seir_sampler_create(model._ctx, ctypes.byref(desc), ctypes.byref(self._s)))
 
     def close(self):
+        for bf in getattr(self, "_pinned", []):
+            bf.close()
+        self._pinned, self._pinned_key = [], None
         if getattr(self, "_s", None) is not None and self._s:
             self._lib.seir_sampler_destroy(self._s)
             self._s = ctypes.c_void_p()
@@ -139,12 +177,25 @@ class ChainSampler:
             float(target_accept_prob), *args))
 
     # -- sampling ---------------------------------------------------------------
-    def reset_trace(self):
-        _lib.check(self._lib.seir_sampler_reset_trace(self._s))
+    def reset_trace(self, at: int = 0):
+        """The next sweep is recorded in trace slot `at` (0: start of the burst buffer)."""
+        if at:
+            _lib.check(self._lib.seir_sampler_reset_trace_at(self._s, int(at)))
+        else:
+            _lib.check(self._lib.seir_sampler_reset_trace(self._s))
 
     def run(self, num_sweeps: int):
         """Enqueue sweeps (asynchronous)."""
         _lib.check(self._lib.seir_sampler_run(self._s, int(num_sweeps)))
+
+    def _as_trace(self, n, theta, ev, hmc, mv) -> Trace:
+        hmc_d = dict(is_accepted=hmc[..., 0] != 0, target_log_prob=hmc[..., 1], step_size=hmc[..., 2])
+        moves = {}
+        for i, key in enumerate(MOVE_KEYS):
+            delta = mv[:, :, i, 2:].reshape(n, self.B, 4, _lib.MMAX)[..., :self.mmax]
+            moves[key] = dict(is_accepted=mv[:, :, i, 0] != 0, target_log_prob=mv[:, :, i, 1],
+                              proposed_delta=delta.astype(np.int64))
+        return Trace(theta=theta, events=ev, hmc=hmc_d, moves=moves)
 
     def read_trace(self, count: int, first: int = 0, events: bool = True) -> Trace:
         n = int(count)
@@ -155,13 +206,69 @@ class ChainSampler:
         _lib.check(self._lib.seir_sampler_read_trace(
             self._s, int(first), n, _dptr(theta),
             None if ev is None else ev.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dptr(hmc), _dptr(mv)))
-        hmc_d = dict(is_accepted=hmc[..., 0] != 0, target_log_prob=hmc[..., 1], step_size=hmc[..., 2])
-        moves = {}
-        for i, key in enumerate(MOVE_KEYS):
-            delta = mv[:, :, i, 2:].reshape(n, self.B, 4, _lib.MMAX)[..., :self.mmax]
-            moves[key] = dict(is_accepted=mv[:, :, i, 0] != 0, target_log_prob=mv[:, :, i, 1],
-                              proposed_delta=delta.astype(np.int64))
-        return Trace(theta=theta, events=ev, hmc=hmc_d, moves=moves)
+        return self._as_trace(n, theta, ev, hmc, mv)
+
+    def read_trace_async(self, count: int, first: int, into: PinnedTrace):
+        """Enqueue the device->host copy of trace slots [first, first+count) behind the sweeps queued so far;
+        returns at once.  `trace_wait()` then `trace_view(into, count)` give the burst."""
+        n = int(count)
+        if n > into.count:
+            raise ValueError("pinned buffer too small")
+        _lib.check(self._lib.seir_sampler_read_trace_async(
+            self._s, int(first), n, _dptr(into.theta),
+            None if into.events is None else into.events.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            _dptr(into.hmc), _dptr(into.moves)))
+
+    def trace_wait(self):
+        _lib.check(self._lib.seir_sampler_trace_wait(self._s))
+
+    def trace_view(self, buf: PinnedTrace, count: int) -> Trace:
+        n = int(count)
+        return self._as_trace(n, buf.theta[:n], None if buf.events is None else buf.events[:n], buf.hmc[:n],
+                              buf.moves[:n])
+
+    def sample_bursts(self, num_bursts: int, burst: int, consume, events: bool = True):
+        """`num_bursts` x `burst` sweeps with the burst buffer used as two halves: while burst k+1 runs on
+        the device, burst k crosses PCIe into page-locked memory on a copy stream and `consume(trace, k)`
+        (e.g. the HDF5 writer) runs on a worker thread -- the sampler only waits when the consumer is
+        the slower side.  Needs trace_capacity >= 2 * burst.  The trace handed to `consume` is a view of a
+        pinned buffer that is re-used two bursts later: copy what must outlive the call."""
+        from concurrent.futures import ThreadPoolExecutor
+        burst, num_bursts = int(burst), int(num_bursts)
+        if 2 * burst > self.cap:
+            raise ValueError(f"sample_bursts needs trace_capacity >= 2 * burst = {2 * burst}, have {self.cap}")
+        # page-locking GBs of host memory takes tenths of a second: the two buffers are kept for the next call
+        key = (burst, bool(events))
+        if getattr(self, "_pinned_key", None) != key:
+            for bf in getattr(self, "_pinned", []):
+                bf.close()
+            self._pinned = [PinnedTrace(self, burst, events), PinnedTrace(self, burst, events)]
+            self._pinned_key = key
+        bufs = self._pinned
+        futs = [None, None]
+        prev = -1
+        try:
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                for i in range(num_bursts):
+                    h = i & 1
+                    if futs[h] is not None:
+                        futs[h].result()                 # the consumer is done with host buffer h
+                        futs[h] = None
+                    self.reset_trace(at=h * burst)
+                    self.run(burst)                      # asynchronous
+                    if prev >= 0:
+                        self.trace_wait()                # burst i-1 has landed (it crossed while burst i ran)
+                        futs[prev & 1] = pool.submit(consume, self.trace_view(bufs[prev & 1], burst), prev)
+                    self.read_trace_async(burst, h * burst, bufs[h])
+                    prev = i
+                if prev >= 0:
+                    self.trace_wait()
+                    futs[prev & 1] = pool.submit(consume, self.trace_view(bufs[prev & 1], burst), prev)
+                for f in futs:
+                    if f is not None:
+                        f.result()
+        finally:
+            self.trace_wait()
 
     def sample(self, num_sweeps: int, events: bool = True) -> Trace:
         """reset_trace + run + read: the analogue of one `sample_chain` call."""

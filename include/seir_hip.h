@@ -214,6 +214,9 @@ int seir_sampler_refresh(seir_sampler *s);
 
 /* Start a new burst: trace slot 0 = the next sweep. */
 int seir_sampler_reset_trace(seir_sampler *s);
+/* The same with the next sweep recorded in slot `first_slot`: a burst buffer of 2 n slots used as two
+ * halves lets burst k+1 run while burst k leaves the device (seir_sampler_read_trace_async). */
+int seir_sampler_reset_trace_at(seir_sampler *s, int32_t first_slot);
 /* Enqueue num_sweeps sweeps on the context stream (asynchronous). */
 int seir_sampler_run(seir_sampler *s, int32_t num_sweeps);
 /* Blocking read of trace slots [first, first+count):
@@ -225,6 +228,20 @@ int seir_sampler_run(seir_sampler *s, int32_t num_sweeps);
  *          inference.py:262-280) */
 int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, double *theta, int32_t *events,
                             double *hmc, double *moves);
+
+/* Overlapped egress of a burst (the reference's per-burst posterior.write_samples, inference.py:453-468,
+ * without stalling the sampler): the copies are enqueued on a dedicated copy stream behind everything
+ * already queued on the context stream and the call returns at once; sweeps enqueued afterwards run
+ * concurrently with the transfer.  Arguments as seir_sampler_read_trace; the host buffers should be
+ * page-locked (seir_host_alloc) -- pageable memory works but serialises.  seir_sampler_trace_wait
+ * blocks until the last async read has landed; call it before touching the host buffers and before
+ * re-using the trace slots being read. */
+int seir_sampler_read_trace_async(seir_sampler *s, int32_t first, int32_t count, double *theta, int32_t *events,
+                                  double *hmc, double *moves);
+int seir_sampler_trace_wait(seir_sampler *s);
+/* Page-locked host memory for the calls above. */
+int seir_host_alloc(void **host_ptr, uint64_t bytes);
+int seir_host_free(void *host_ptr);
 
 /* Mean launch duration (ms, HIP events on the context stream) of the sweep's
  * gradient kernel -- the S->E term + d/d eta sums over all B chains that runs

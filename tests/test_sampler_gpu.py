@@ -441,3 +441,31 @@ def test_sampler_argument_errors(api):
             bad[0, 0, 0, 0] = 0.5
             with pytest.raises(_lib.SeirError):
                 s.set_state(case["u"][None], bad)
+
+
+def test_overlapped_bursts_deliver_the_same_draws(api):
+    """sample_bursts (burst buffer in two halves, copies on a second stream into page-locked memory, consumer
+    on a worker thread) against plain blocking reads of the same sweeps: identical draws, in order."""
+    SeirModel, ChainSampler = api
+    case = H.build_case("micro_17x70", 9, alpha_t_sd=0.005)
+    B, burst, nb = 3, 7, 5
+    u, ev = _start(case, B, 9)
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, CFG_SMALL, B, seed=5, trace_capacity=burst * nb) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.0004)
+            ref = s.sample(burst * nb)
+        got = []
+        with ChainSampler(model, CFG_SMALL, B, seed=5, trace_capacity=2 * burst) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=0.0004)
+            s.sample_bursts(nb, burst, lambda tr, i: got.append((i, tr.theta.copy(), tr.events.copy(),
+                                                                  tr.hmc["target_log_prob"].copy(),
+                                                                  tr.moves["move/E->I"]["proposed_delta"].copy())))
+            with pytest.raises(ValueError):
+                s.sample_bursts(1, burst + 1, lambda tr, i: None)
+    assert [g[0] for g in got] == list(range(nb))
+    assert np.array_equal(np.concatenate([g[1] for g in got]), ref.theta)
+    assert np.array_equal(np.concatenate([g[2] for g in got]), ref.events)
+    assert np.array_equal(np.concatenate([g[3] for g in got]), ref.hmc["target_log_prob"])
+    assert np.array_equal(np.concatenate([g[4] for g in got]), ref.moves["move/E->I"]["proposed_delta"])
