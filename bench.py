@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--chains-per-gpu", type=int, default=8)
     ap.add_argument("--adapt-sweeps", type=int, default=60, help="untimed dual-averaging sweeps during setup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end (HDF5-writing) single-chain measurement")
     ap.add_argument("--no-chains-scaling", action="store_true",
                     help="skip the extra (untimed-by-the-contract) runs at 32 and 64 chains on this GPU")
     ap.add_argument("--cpu-baseline-sweeps", type=int, default=0, help="0 = size for ~10 s per leg")
@@ -283,6 +284,38 @@ def main():
             sx.close()
             mx.close()
 
+    # the drop-in surface end to end (N=1 only): the sampling phase of run_mcmc for ONE chain, as the reference runs
+    # it, every draw written to posterior.hd5 in the reference's schema (samples/seir float64 [n,M,T,3]: 3.3 MB per
+    # draw at UK-380) -- warm-up excluded, device->host->HDF5 included
+    cli = None
+    if world == 1 and not a.no_cli and a.workload == "uk380":
+        import tempfile
+        from covid19uk_amd.inference import inference as inf
+        m1 = SeirModel(cov, init, max_chains=1, device=local)
+        s1 = ChainSampler(m1, MCMC_CONFIG, 1, seed=a.seed, trace_capacity=100, record_events=True)
+        s1.set_state(u_all[:1], ev0[:1])
+        s1.set_kernel(step_size=pooled)
+        nbc, nsc = 6, 50
+        with tempfile.TemporaryDirectory() as tmp:
+            post = inf.Posterior(os.path.join(tmp, "posterior.hd5"), M, T, MCMC_CONFIG["m"], nbc * nsc, burst=nsc)
+            off = [0]
+
+            def flush(tr_, i):
+                post.write_samples(inf.draws_to_dict(tr_.theta, tr_.events, 0), first_dim_offset=off[0])
+                post.write_results(inf.trace_to_dict(tr_, 0), first_dim_offset=off[0])
+                off[0] += tr_.theta.shape[0]
+            s1.sample_bursts(2, nsc, lambda tr_, i: None)          # untimed: page-locks the host buffers
+            t3 = time.perf_counter()
+            s1.sample_bursts(nbc, nsc, flush)
+            dt_cli = time.perf_counter() - t3
+            post.close()
+            cli = {"value": nbc * nsc / dt_cli, "unit": "posterior samples/sec", "chains": 1,
+                   "format": "hdf5" if post.use_h5 else "npz (no libhdf5 on this host)",
+                   "bytes_written": nbc * nsc * (8 * (3 * M * T + P) + 200),
+                   "note": f"{nbc} bursts x {nsc} draws through ChainSampler.sample_bursts + Posterior (inference.py:453-468)"}
+        s1.close()
+        m1.close()
+
     if rank == 0:
         out = {
             "metric": "posterior samples/sec, 380-LAD UK SEIR" if a.workload == "uk380"
@@ -317,6 +350,8 @@ def main():
             "pcie_serial_samples_per_sec": world * B * K / (elapsed + d2h),
             "acceptance": acc, "step_size": pooled, "all_log_probs_finite": finite,
         }
+        if cli:
+            out["cli_samples_per_sec"] = cli
         if scaling:
             out["chains_per_gpu_scaling"] = scaling
         if not a.no_cpu_baseline:

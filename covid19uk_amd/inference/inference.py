@@ -190,7 +190,7 @@ def trace_to_dict(tr, chain):
     return out
 
 
-def run_mcmc(sampler: ChainSampler, config, posteriors, log=sys.stderr):
+def run_mcmc(sampler: ChainSampler, config, posteriors, log=sys.stderr, pool_step_size=False):
     """The windowed schedule of inference.py:303-470: fast 200, slow 25*2^k (k<6), fast 50,
     then num_bursts x num_burst_samples with the kernel fixed.  Every draw -- warm-up
     included -- is written, as in the reference."""
@@ -225,6 +225,12 @@ def run_mcmc(sampler: ChainSampler, config, posteriors, log=sys.stderr):
 
     print("Sampling...", file=log, flush=True)
     step_size = tr.hmc["step_size"][(-last_window_size) // 2:].mean(axis=0)      # inference.py:439-441
+    if pool_step_size:
+        # build extension (the reference is single-chain): every chain of the job -- all ranks -- samples with
+        # the geometric mean of the adapted step sizes; one float64 per chain over RCCL / gloo
+        from .. import distributed as D
+        step_size = np.full(sampler.B, D.pool_step_sizes(step_size, device=sampler.model.device))
+        print(f"Pooled step size over all chains: {step_size[0]:.4g}", file=log, flush=True)
     sampler.set_adaptation(adapt_step_size=False)
     sampler.set_kernel(step_size=step_size, variance=sampler.get_kernel()[1])
     nb, ns = int(config["num_bursts"]), int(config["num_burst_samples"])
@@ -251,35 +257,68 @@ def warmup_size():
     return 200 + 25 * (2 ** 6 - 1) + 50          # inference.py:312-322
 
 
-def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=0):
-    """Constructs and runs the MCMC (covid19uk/inference/inference.py:473-608)."""
+def job_layout(num_chains, device=None, env=os.environ):
+    """Where this process sits in a multi-GPU job: one process per GPU (torchrun / torch.distributed.run
+    sets RANK, WORLD_SIZE, LOCAL_RANK), `num_chains` chains on each.  Read from the environment only --
+    nothing here touches the GPU.  Returns dict(rank, world, device, first_chain_id)."""
+    rank, world = int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
+    if not (0 <= rank < world):
+        raise ValueError(f"RANK={rank} outside WORLD_SIZE={world}")
+    dev = int(env.get("LOCAL_RANK", "0")) if device is None else int(device)
+    return dict(rank=rank, world=world, device=dev, first_chain_id=rank * int(num_chains))
+
+
+def chain_file_name(output_file, chain, total_chains):
+    """posterior.hd5 for a single-chain job (the reference); posterior_chain{c}.hd5 with the GLOBAL chain id otherwise."""
+    if total_chains == 1:
+        return output_file
+    root, ext = os.path.splitext(output_file)
+    return f"{root}_chain{chain}{ext}"
+
+
+def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool_step_size=False):
+    """Constructs and runs the MCMC (covid19uk/inference/inference.py:473-608).
+
+    Multi-GPU: launched as one process per GPU, every rank runs `num_chains` chains with
+    global ids rank*num_chains ... (the Philox streams are keyed by the global id, so the draws of chain c
+    do not depend on how the job is sharded) and writes its own posterior_chain{c}.hd5; there is no
+    data-path collective.  `pool_step_size` adds the one optional exchange: an all_gather of one float64
+    per chain after warm-up."""
+    lay = job_layout(num_chains, device)                    # before any GPU call
     cov, cases, dates = read_inference_data(data_file)
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed)                       # same imputation on every rank: one initial state per job
     B = int(num_chains)
-    inits, evs = zip(*[model_spec.initial_conditions(cases, cov.N, rng) for _ in range(1)])
-    initial_state, events = inits[0], evs[0]
+    initial_state, events = model_spec.initial_conditions(cases, cov.N, rng)
     M, T = events.shape[0], events.shape[1]
     P = model_spec.num_params(M, T)
     cfg = event_kernel_config(config)
     num_samples = warmup_size() + int(config["num_burst_samples"]) * int(config["num_bursts"])
     cap = max(800, 2 * int(config["num_burst_samples"]))      # two halves: a burst runs while the previous one is written
 
-    model = SeirModel(cov, initial_state, max_chains=B, device=device)
+    if lay["world"] > 1 and pool_step_size:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("SEIR_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                torch.cuda.set_device(lay["device"])
+                dist.init_process_group("nccl", device_id=torch.device("cuda", lay["device"]))
+            else:
+                dist.init_process_group(backend)
+    model = SeirModel(cov, initial_state, max_chains=B, device=lay["device"])
     sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),
                            num_leapfrog_steps=hmc_kernel_kwargs_default()["num_leapfrog_steps"],
-                           trace_capacity=cap, record_events=True)
+                           trace_capacity=cap, record_events=True, first_chain_id=lay["first_chain_id"])
     u0 = np.zeros((B, P))                                   # inference.py:563-573
     sampler.set_state(u0, np.stack([events] * B))
     print("Initial logpi:", sampler.log_prob(), flush=True)
 
-    def out_name(c):
-        if B == 1:
-            return output_file
-        root, ext = os.path.splitext(output_file)
-        return f"{root}_chain{c}{ext}"
-    posteriors = [Posterior(out_name(c), M, T, cfg["m"], num_samples, burst=int(config["num_burst_samples"]))
-                  for c in range(B)]
-    run_mcmc(sampler, config, posteriors)
+    total = lay["world"] * B
+    names = [chain_file_name(output_file, lay["first_chain_id"] + c, total) for c in range(B)]
+    posteriors = [Posterior(name, M, T, cfg["m"], num_samples, burst=int(config["num_burst_samples"]))
+                  for name in names]
+    run_mcmc(sampler, config, posteriors, pool_step_size=pool_step_size and total > 1)
     for post in posteriors:
         post.create_dataset("initial_state", initial_state)
         n = max(len(s) for s in dates)
@@ -290,6 +329,12 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=0):
         post.close()
     sampler.close()
     model.close()
+    if lay["world"] > 1 and pool_step_size:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    return names
 
 
 def main(argv=None):
@@ -301,12 +346,15 @@ def main(argv=None):
     parser.add_argument("-o", "--output", type=str, help="Output file", required=True)
     parser.add_argument("data_file", type=str, help="Data NetCDF file")
     parser.add_argument("--seed", type=int, default=0, help="RNG seed (the reference is unseeded)")
-    parser.add_argument("--chains", type=int, default=1, help="independent chains on this GPU")
-    parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--chains", type=int, default=1, help="independent chains on this GPU (per rank under torchrun)")
+    parser.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, 0 outside torchrun)")
+    parser.add_argument("--pool-step-size", action="store_true",
+                        help="sample with the geometric mean of all chains' adapted HMC step sizes (one all_gather)")
     args = parser.parse_args(argv)
     with open(args.config, "r") as f:
         config = yaml.load(f, Loader=yaml.FullLoader)
-    mcmc(args.data_file, args.output, config["Mcmc"], seed=args.seed, num_chains=args.chains, device=args.device)
+    mcmc(args.data_file, args.output, config["Mcmc"], seed=args.seed, num_chains=args.chains, device=args.device,
+         pool_step_size=args.pool_step_size)
 
 
 if __name__ == "__main__":

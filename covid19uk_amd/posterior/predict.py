@@ -114,7 +114,7 @@ def predict(data, posterior_samples, output_file, initial_step, num_steps, out_o
     return init, events
 
 
-if __name__ == "__main__":
+def main(argv=None):
     from argparse import ArgumentParser
     parser = ArgumentParser()
     parser.add_argument("-i", "--initial-step", type=int, default=0, help="Initial step")
@@ -125,6 +125,10 @@ if __name__ == "__main__":
     parser.add_argument("data_pkl", type=str, help="Inference-data file")
     parser.add_argument("posterior_samples_pkl", type=str, help="Posterior samples pickle")
     parser.add_argument("output_file", type=str, help="Output file")
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
     predict(args.data_pkl, args.posterior_samples_pkl, args.output_file, args.initial_step, args.num_steps,
             args.out_of_sample, seed=args.seed)
+
+
+if __name__ == "__main__":
+    main()

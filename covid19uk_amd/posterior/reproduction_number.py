@@ -46,11 +46,15 @@ def reproduction_number(input_files, output_file, device=0):
     return r_it, r_t
 
 
-if __name__ == "__main__":
+def main(argv=None):
     from argparse import ArgumentParser
     parser = ArgumentParser()
     parser.add_argument("samples", type=str, help="A pickle file with MCMC samples")
     parser.add_argument("-d", "--data", type=str, help="The inference-data file", required=True)
     parser.add_argument("-o", "--output", type=str, help="The output file", required=True)
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
     reproduction_number([args.data, args.samples], args.output)
+
+
+if __name__ == "__main__":
+    main()

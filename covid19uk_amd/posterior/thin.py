@@ -42,7 +42,7 @@ def thin_posterior(input_file, output_file, config):
     return out
 
 
-if __name__ == "__main__":
+def main(argv=None):
     import argparse
 
     import yaml
@@ -50,7 +50,11 @@ if __name__ == "__main__":
     parser.add_argument("-c", "--config", type=str, required=True, help="Configuration file")
     parser.add_argument("-o", "--output", type=str, required=True, help="Output pkl file")
     parser.add_argument("samples", type=str, help="MCMC samples file (posterior.hd5)")
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
     with open(args.config, "r") as f:
         cfg = yaml.load(f, Loader=yaml.FullLoader)
     thin_posterior(args.samples, args.output, cfg["ThinPosterior"])
+
+
+if __name__ == "__main__":
+    main()

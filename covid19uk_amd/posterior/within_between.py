@@ -39,11 +39,15 @@ def within_between(input_files, output_file, device=0):
     return within, between
 
 
-if __name__ == "__main__":
+def main(argv=None):
     from argparse import ArgumentParser
     parser = ArgumentParser()
     parser.add_argument("-d", "--datafile", type=str, help="Inference-data file", required=True)
     parser.add_argument("-s", "--samples", type=str, help="Posterior samples pickle", required=True)
     parser.add_argument("-o", "--output", type=str, help="Output csv")
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
     within_between([args.datafile, args.samples], args.output)
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,11 @@ def main():
     dist.init_process_group("gloo")
     rank, ws = D.world()
     first, count = D.shard_chains(total, ws, rank)
+    # the product driver's view of the same job (covid19uk_amd.inference.inference.mcmc): environment only
+    from covid19uk_amd.inference import inference as inf
+    lay = inf.job_layout(4)
+    assert (lay["rank"], lay["world"], lay["first_chain_id"]) == (rank, ws, 4 * rank)
+    assert inf.chain_file_name("p.hd5", lay["first_chain_id"] + 1, 4 * ws) == f"p_chain{4 * rank + 1}.hd5"
     local_eps = np.array([1e-3 * (c + 1) for c in range(first, first + count)])
     gathered = D.gather_chain_values(local_eps)
     pooled = D.pool_step_sizes(local_eps)

@@ -54,3 +54,55 @@ def test_cli_end_to_end_ni11(tmp_path):
         assert abs(g0.mean() - truth["gamma0"]) < 0.35, g0.mean()     # I->R rate is well identified
         psi = f.read("/samples/psi")
         assert (psi > 0).all()
+
+
+def test_two_rank_job_equals_one_process_with_all_chains(tmp_path):
+    """SURVEY.md 8e through the product driver: chains {0..3} run as 2 + 2 in two processes (RANK /
+    WORLD_SIZE as torchrun sets them; both ranks share this box's one GPU, the step-size exchange goes over
+    gloo) must write the same posterior_chain{c}.hd5 files, bit for bit, as one process running all four --
+    the draws of a chain depend on its global id only, and the pooled step size on all chains of the job."""
+    import socket
+    cov = synth.make_covariates("ni11")
+    events, init, truth = synth.simulate_epidemic(cov)
+    data = str(tmp_path / "inferencedata.nc")
+    inf.write_inference_data(data, cov, events[..., 2])
+    cfg = {"Mcmc": dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5,
+                        num_bursts=2, num_burst_samples=40, thin=1)}
+    cfg_path = str(tmp_path / "config.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    base = [sys.executable, "-m", "covid19uk.inference.inference", "-c", cfg_path, "--seed", "11",
+            "--pool-step-size", "--device", "0"]
+    env = dict(os.environ, PYTHONPATH=H.ROOT)
+    one = tmp_path / "one"
+    one.mkdir()
+    r = subprocess.run(base + ["--chains", "4", "-o", str(one / "posterior.hd5"), data], cwd=H.ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = tmp_path / "two"
+    two.mkdir()
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port), SEIR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(base + ["--chains", "2", "-o", str(two / "posterior.hd5"), data], cwd=H.ROOT,
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err[-2000:]
+        assert "Pooled step size" in err
+    n = 1825 + 80
+    for c in range(4):
+        with hdf5io.File(str(one / f"posterior_chain{c}.hd5"), "r") as fa, \
+                hdf5io.File(str(two / f"posterior_chain{c}.hd5"), "r") as fb:
+            for name in ("/samples/psi", "/samples/alpha_t", "/samples/spatial_effect", "/samples/seir",
+                         "/results/hmc/target_log_prob", "/results/hmc/step_size", "/results/move/E->I/proposed_delta",
+                         "/results/occult/S->E/is_accepted"):
+                a, b = fa.read(name), fb.read(name)
+                assert a.shape[0] == n and np.array_equal(a, b), (c, name)
+    # the chains are different chains
+    with hdf5io.File(str(two / "posterior_chain0.hd5"), "r") as fa, hdf5io.File(str(two / "posterior_chain3.hd5"), "r") as fb:
+        assert not np.array_equal(fa.read("/samples/psi"), fb.read("/samples/psi"))

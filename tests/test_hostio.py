@@ -137,3 +137,35 @@ def test_hyperslab_row_reads(tmp_path):
         assert f.read_rows("g/a", 0, 0).shape == (0, 4, 3)
         with pytest.raises(ValueError):
             f.read_rows("g/a", 5, 4, 2)
+
+
+def test_reference_module_paths_resolve():
+    """covid19uk/__init__.py:3-21 and the `python -m covid19uk.<stage>` entry points of the reference
+    (thin.py:24-43, predict.py:149-182, reproduction_number.py:91-107, within_between.py:95-113)."""
+    import importlib
+    import subprocess
+    import sys
+    import covid19uk
+    for name in ("mcmc", "thin_posterior", "reproduction_number", "predict", "within_between"):
+        assert callable(getattr(covid19uk, name)), name
+    for mod, fn in (("thin", "thin_posterior"), ("predict", "predict"), ("reproduction_number", "reproduction_number"),
+                    ("within_between", "within_between")):
+        m = importlib.import_module(f"covid19uk.posterior.{mod}")
+        assert callable(getattr(m, fn))
+        out = subprocess.run([sys.executable, "-m", f"covid19uk.posterior.{mod}", "--help"], capture_output=True,
+                             text=True, cwd=H.ROOT if "H" in globals() else None)
+        assert out.returncode == 0 and "usage" in out.stdout.lower(), (mod, out.stderr[-300:])
+    out = subprocess.run([sys.executable, "-m", "covid19uk.inference.inference", "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--pool-step-size" in out.stdout
+
+
+def test_job_layout_and_chain_file_names():
+    # SURVEY.md 8e: one process per GPU, rank r runs global chains r*B .. r*B+B-1 and writes posterior_chain{c}.hd5
+    lay = inf.job_layout(8, env={"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3"})
+    assert lay == dict(rank=3, world=8, device=3, first_chain_id=24)
+    assert inf.job_layout(1, env={}) == dict(rank=0, world=1, device=0, first_chain_id=0)
+    assert inf.job_layout(2, device=5, env={"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1"})["device"] == 5
+    with pytest.raises(ValueError):
+        inf.job_layout(1, env={"RANK": "2", "WORLD_SIZE": "2"})
+    assert inf.chain_file_name("out/posterior.hd5", 0, 1) == "out/posterior.hd5"
+    assert inf.chain_file_name("out/posterior.hd5", 25, 64) == "out/posterior_chain25.hd5"
