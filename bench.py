@@ -182,7 +182,7 @@ def main():
 
     # the same sweeps with every draw leaving the device: bursts of `burst` sweeps, each crossing PCIe into
     # page-locked memory on a copy stream while the next one runs (ChainSampler.sample_bursts; what the CLI does)
-    n_bursts = max(8, K // burst)
+    n_bursts = max(16, K // burst)
     touched = []
     sampler.sample_bursts(2, burst, lambda tr_, i: None)          # untimed: page-locks the two host buffers
     t2 = time.perf_counter()

@@ -169,3 +169,23 @@ def test_job_layout_and_chain_file_names():
         inf.job_layout(1, env={"RANK": "2", "WORLD_SIZE": "2"})
     assert inf.chain_file_name("out/posterior.hd5", 0, 1) == "out/posterior.hd5"
     assert inf.chain_file_name("out/posterior.hd5", 25, 64) == "out/posterior_chain25.hd5"
+
+
+def test_reads_a_file_with_the_layout_xarray_writes():
+    """f-1: a netCDF-4 file laid out as `assemble_data` writes it (assemble.py:15-16, model_spec.py:88-105:
+    groups, dimension scales, variable-length string coordinates, int64 `days since` time with CF attributes,
+    NaN _FillValue, chunked + shuffled + deflated variables, int64 case counts) -- generated with h5py by
+    tests/golden/make_netcdf_fixture.py, i.e. NOT by this package's own writer."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "inferencedata_xarray_layout.nc")
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "inferencedata_expected.npz"))
+    cov, cases, dates = inf.read_inference_data(path)
+    for k in ("C", "N", "W", "adjacency", "weekday", "area"):
+        assert np.array_equal(getattr(cov, k), want[k]), k
+        assert getattr(cov, k).dtype == np.float64
+    assert np.array_equal(cases, want["cases"]) and cases.dtype == np.float64
+    assert dates == [str(x) for x in want["time"]]
+    # and the data preparation of inference.py:481-513 runs on it
+    init, events = ms.initial_conditions(cases, cov.N, np.random.default_rng(0))
+    assert events.shape == (cov.M, cov.T, 3) and init.shape == (cov.M, 4)
+    assert np.array_equal(events[..., 2], cases)
