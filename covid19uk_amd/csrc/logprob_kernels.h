@@ -23,6 +23,7 @@ namespace seir {
 constexpr int SCAN_ROWS = 8;    // rows per k_scan workgroup
 constexpr int SCAN_WAVES = 8;   // one row per wave: 3 waves per SIMD at UK-380 x 8 chains, evenly
 constexpr int SCAN_CB = 6;      // k_scan: 64-day chunks fetched per batch (6 = one batch at T <= 384)
+constexpr int SCAN_LFT = 2048;  // k_scan: entries of the log-factorial table held in LDS (16 KB)
 constexpr int SE_RW = 4;        // k_se: rows per wave; tile = (4*SE_RW) rows x 64 days per workgroup
 constexpr int SE_TM = 4 * SE_RW;
 constexpr int NSCAL = 16;       // per-chain scalar block
@@ -55,12 +56,15 @@ __device__ __forceinline__ void debug_skew(const Dims &d) {
 
 struct Consts {
     const double *Cstar;   // [Mp][Kp0], Kp0 = Mp: zero-padded, symmetric
+    const float *Cstar32;  // the same rounded to fp32 (k_gemm_f32; allocated when SEIR_OPT_GEMM_F32 is first set)
     const double *N, *invN, *la;   // [Mp]
     const double *W, *wd;          // [Tp]
     const double *init;            // [Mp][4]
     const int *Qrow, *Qcol;        // CSR of car_Q
     const double *Qval;
     const double2 *logtab;         // [LDSTAB_N] (1/c, log c) of device_math.h fast_log, then log(n!) pairs
+    const double *lfact_big;       // [SCAN_LFT] log(n!) for n < SCAN_LFT: k_scan's LDS table (E, I and the event counts
+                                   //            are mostly below it; Stirling above)
     int qw;                        // ELL width of car_Q (0: use the CSR arrays)
     const int *Qell_col;           // [qw][Mp]
     const double *Qell_val;        // [qw][Mp]
@@ -68,6 +72,7 @@ struct Consts {
 
 struct Work {
     double *Xn, *F;        // [B][Mp][Tp]
+    float *Xn32;           // [B][Mp][Tp] I/N rounded to fp32 for k_gemm_f32 (null unless SEIR_OPT_GEMM_F32 was set)
     int2 *KS;              // [B][Mp][Tp]
     int *K[3], *St[3];     // sampler planes [B][Mp][Tp] (null on a plain context)
     int *rowtot;           // [B][2][Mp] row totals of S->E / E->I events (sampler)
@@ -105,14 +110,19 @@ constexpr int GST_N = 16;       // q[0..5], p[0..5], psi, sigma_space, sigmoid(u
 // SRC 1: events from the sampler's int32 planes; writes St planes, Xn, rowtot.
 // ---------------------------------------------------------------------------
 template <int SRC>
-__global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
-    extern __shared__ double lds[];                 // [SCAN_WAVES][Tp][2]
+__device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const Work &w, const double *__restrict__ events) {
+    extern __shared__ double lds[];                 // [SCAN_WAVES][Tp][2] | lft [SCAN_LFT]
     __shared__ double2 ltab[LDSTAB_N];
     debug_skew(d);
     const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *mycol = lds + (size_t)wave * d.Tp * 2;
+    double *lft = lds + (size_t)SCAN_WAVES * d.Tp * 2;
+    for (int i = threadIdx.x; i < SCAN_LFT; i += SCAN_WAVES * WAVE) lft[i] = c.lfact_big[i];
     for (int i = lane; i < d.Tp * 2; i += WAVE) mycol[i] = 0.0;
     log_table_to_lds(ltab, c.logtab);
+    // log(n!): LDS table below SCAN_LFT (one ds_read instead of ~40 dependent fp64 operations), Stirling above
+    auto lf = [&](double n) { return n < (double)SCAN_LFT ? lft[(int)n] : lfact(n, ltab); };
+    auto lb = [&](double n, double k) { return (k < 0.0 || k > n) ? -INFINITY : lf(n) - lf(k) - lf(n - k); };
 
     const double r_ei = d.nu * d.dt;
     const double L_ei = d.L_ei;
@@ -159,6 +169,7 @@ __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Wo
                 const double xse = cse + ise - kse[j], xei = cei + iei - kei[j], xir = cir + iir - kir[j];
                 const double S = S0 - xse, E = E0 + xse - xei, I = I0 + xei - xir;
                 w.Xn[rowoff + t] = valid ? I * invN : 0.0;
+                if (w.Xn32 != nullptr) w.Xn32[rowoff + t] = valid ? (float)(I * invN) : 0.f;
                 if (SRC == 0) {
                     w.KS[rowoff + t] = valid ? make_int2((int)kse[j], (int)(S - kse[j])) : make_int2(0, 0);
                 } else {
@@ -167,7 +178,12 @@ __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Wo
                     w.St[2][rowoff + t] = valid ? (int)I : 0;
                 }
                 if (valid) {
-                    rc += lbinom(S, kse[j], ltab) + lbinom(E, kei[j], ltab) + lbinom(I, kir[j], ltab);
+                    // S only ever loses its events (S_{t+1} = S_t - k_t), so its binomial coefficients telescope:
+                    //   sum_t [lf(S_t) - lf(k_t) - lf(S_t - k_t)] = lf(S_0) - lf(S_T) - sum_t lf(k_t)
+                    // -- one small-argument term per cell here, the two large ones once per row below; E and I
+                    // also gain events and do not telescope.  Infeasible counts (k < 0 or k > S) still give -inf.
+                    rc += (kse[j] < 0.0 || kse[j] > S) ? -INFINITY : -lf(kse[j]);
+                    rc += lb(E, kei[j]) + lb(I, kir[j]);
                     rc += kei[j] * L_ei - (E - kei[j]) * r_ei;
                     mycol[t * 2 + 0] += kir[j];
                     mycol[t * 2 + 1] += I - kir[j];
@@ -179,6 +195,8 @@ __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Wo
         }
         rc = wave_sum(rc);
         if (lane == 0) {
+            // the telescoped ends (cse = all S->E events of the row); an exhausted S already produced -inf above
+            rc += S0 - cse >= 0.0 ? lfact(S0, ltab) - lfact(S0 - cse, ltab) : -INFINITY;
             w.rowconst[(size_t)b * d.Mp + m] = rc;
             if (SRC == 1) {
                 w.rowtot[((size_t)b * 2 + 0) * d.Mp + m] = (int)cse;
@@ -197,14 +215,19 @@ __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Wo
     }
 }
 
+template <int SRC>
+__global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
+    scan_rows<SRC>(d, c, w, events);
+}
+
 // Grid (Tp/64, chains): Kir_t, Dir_t of 64 days per workgroup (integer-valued, exact in any
 // order); block 0 of a chain also sums the row constants.
-__global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) {
+__device__ __forceinline__ void colreduce_block(const Dims &d, const Work &w, int bx, int by) {
     __shared__ double sh[4];
     __shared__ double2 part[4][WAVE];
     debug_skew(d);
-    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * WAVE + lane;
+    const int b = d.b0 + by, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = bx * WAVE + lane;
     // wave w folds the partial rows rb = w, w+4, ...; 16 loads in flight per batch
     double a = 0.0, e = 0.0;
     const double2 *p = (const double2 *)w.colIR + (size_t)b * d.nrb_scan * d.Tp + t;
@@ -225,13 +248,14 @@ __global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) {
         w.Kir[(size_t)b * d.Tp + t] = (p0.x + p1.x) + (p2.x + p3.x);
         w.Dir[(size_t)b * d.Tp + t] = (p0.y + p1.y) + (p2.y + p3.y);
     }
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         double acc = 0.0;
         for (int m = threadIdx.x; m < d.M; m += 256) acc += w.rowconst[(size_t)b * d.Mp + m];
         acc = block_sum_256(acc, sh);
         if (threadIdx.x == 0) w.constsum[b] = acc;
     }
 }
+__global__ __launch_bounds__(256) void k_colreduce(Dims d, Work w) { colreduce_block(d, w, blockIdx.x, blockIdx.y); }
 
 // ---------------------------------------------------------------------------
 // k_gemm: F[b] = Cstar[Mp x Kp] . Xn[b][Kp x Tp] for all T at once (the matvec of
@@ -336,6 +360,166 @@ __global__ __launch_bounds__(gemm_threads<TN>()) void k_gemm(Dims d, Consts c, W
                 Fb[(size_t)(m0 + wr * 32 + i * 16 + ak + 4 * r) * d.Tp + t0 + wc * 32 + j * 16 + ar] = acc[i][j][r];
 }
 
+// k_gemm_w8: the 64 x 96 tile with EIGHT waves, 4 (row blocks of 16) x 2 (column groups of 48), i.e.
+// 1 x 3 MFMA tiles per wave.  The six-wave form of k_gemm<96> puts 2,2,1,1 waves on the four SIMDs of
+// a CU and the two doubly loaded SIMDs set the time; eight waves load every SIMD alike (2 each, which
+// also hides more of the fp64 MFMA's issue latency).  Same staging, LDS layout and arithmetic order
+// per output element as k_gemm (K ascending in chunks of 64), so the results are bit-identical.
+template <int NCG>      // column groups per tile: 2 -> 8 waves of 1 x 3 MFMA tiles, 3 -> 12 waves of 1 x 2
+__global__ __launch_bounds__(256 * NCG) void k_gemm_w8(Dims d, Consts c, Work w) {
+    extern __shared__ double lds[];                 // A [KC][RS] | B [KC][RSB]
+    constexpr int TN = 96, NT = 256 * NCG, RSB = gemm_rsb<TN>(), CW = TN / NCG, NJ = CW / 16;
+    debug_skew(d);
+    const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * GEMM_TM, t0 = blockIdx.x * TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave / NCG, wc = wave % NCG;        // row block (16 rows), column group (CW columns)
+    const double *Xb = w.Xn + (size_t)b * d.Mp * d.Tp;
+    double *A = lds, *Bm = lds + GEMM_KC * GEMM_RS;
+    constexpr int EA = GEMM_KC * (GEMM_TM / 2), EB = GEMM_KC * (TN / 2);
+    constexpr int NA = (EA + NT - 1) / NT, NB = (EB + NT - 1) / NT;
+    double2 ra[NA], rb[NB];
+    auto load_chunk = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + i * NT, row = e / (GEMM_TM / 2), col = (e % (GEMM_TM / 2)) * 2, k = kb + row;
+            ra[i] = (e < EA && k < d.Kp) ? *(const double2 *)(c.Cstar + (size_t)k * d.Kp0 + m0 + col) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + i * NT, row = e / (TN / 2), col = (e % (TN / 2)) * 2, k = kb + row;
+            rb[i] = (e < EB && k < d.Kp) ? *(const double2 *)(Xb + (size_t)k * d.Tp + t0 + col) : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + i * NT, row = e / (GEMM_TM / 2), col = (e % (GEMM_TM / 2)) * 2;
+            if (e < EA) *(double2 *)(A + row * GEMM_RS + col) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + i * NT, row = e / (TN / 2), col = (e % (TN / 2)) * 2;
+            if (e < EB) *(double2 *)(Bm + row * RSB + col) = rb[i];
+        }
+    };
+    d4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int ar = lane & 15, ak = lane >> 4;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int kb = 0; kb < d.Kp; kb += GEMM_KC) {
+        const bool more = kb + GEMM_KC < d.Kp;
+        if (more) load_chunk(kb + GEMM_KC);          // in flight behind the MFMAs of this chunk
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KC; kk += 4) {
+            const double a0 = A[(kk + ak) * GEMM_RS + wr * 16 + ar];
+            const double *bp = Bm + (kk + ak) * RSB + wc * CW + ar;
+            double bf[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = bp[16 * j];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[j], acc[j], 0, 0, 0);
+        }
+        __syncthreads();                             // every wave is done with the chunk in LDS
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    double *Fb = w.F + (size_t)b * d.Mp * d.Tp;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Fb[(size_t)(m0 + wr * 16 + ak + 4 * r) * d.Tp + t0 + wc * CW + j * 16 + ar] = acc[j][r];
+}
+
+// k_gemm_f32: the same contraction with fp32 operands on v_mfma_f32_32x32x2_f32 (BASELINE config 5:
+// "fp32 MFMA mobility matvec" at 2048 regions x 730 days).  Cstar is kept as an fp32 copy (Consts::Cstar32),
+// X = I/N is written in fp32 by the state scan (Work::Xn32), products accumulate in fp32 (a k-ordered fmaf chain,
+// cdna_hip_programming.md section 3) and F is written back as fp64 for the fp64 likelihood kernels.  The
+// result carries ~1e-7 relative error in F (measured through the log-prob: tests/test_logprob_gpu.py), which
+// is why it is an option (SEIR_OPT_GEMM_F32) and not the default: the stated 1e-9 needs the fp64 kernel.
+// Tile 128 x 128, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D: col = l&31, row = (r&3) + 8 (r>>2) + 4 (l>>5)); K in chunks of 16 through two LDS buffers (one barrier
+// per chunk; the next chunk's global loads are in flight behind the 32 MFMAs of the current one).
+constexpr int GF_T = 128, GF_KC = 16, GF_RS = GF_T + 4;
+using f16v = __attribute__((ext_vector_type(16))) float;
+__global__ __launch_bounds__(256) void k_gemm_f32(Dims d, Consts c, Work w) {
+    __shared__ float As[2][GF_KC][GF_RS], Bs[2][GF_KC][GF_RS];
+    debug_skew(d);
+    const int b = d.b0 + blockIdx.z, m0 = blockIdx.y * GF_T, t0 = blockIdx.x * GF_T;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const float *Xb = w.Xn32 + (size_t)b * d.Mp * d.Tp;
+    // staging: A and B chunks 16 x 128 floats = 512 float4 each (2 + 2 per thread)
+    float4 ra[2], rb[2];
+    auto load_chunk = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, row = e >> 5, col = (e & 31) * 4, k = kb + row;
+            ra[i] = k < d.Kp ? *(const float4 *)(c.Cstar32 + (size_t)k * d.Kp0 + m0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, row = e >> 5, col = (e & 31) * 4, k = kb + row;
+            rb[i] = k < d.Kp ? *(const float4 *)(Xb + (size_t)k * d.Tp + t0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, row = e >> 5, col = (e & 31) * 4;
+            *(float4 *)&As[buf][row][col] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256, row = e >> 5, col = (e & 31) * 4;
+            *(float4 *)&Bs[buf][row][col] = rb[i];
+        }
+    };
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int ln = lane & 31, lk = lane >> 5;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = 0; kb < d.Kp; kb += GF_KC) {
+        const bool more = kb + GF_KC < d.Kp;
+        if (more) load_chunk(kb + GF_KC);
+#pragma unroll
+        for (int kk = 0; kk < GF_KC; kk += 2) {
+            const float a0 = As[buf][kk + lk][wr * 64 + ln], a1 = As[buf][kk + lk][wr * 64 + 32 + ln];
+            const float b0 = Bs[buf][kk + lk][wc * 64 + ln], b1 = Bs[buf][kk + lk][wc * 64 + 32 + ln];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);              // the other buffer: nobody reads it during this chunk
+        __syncthreads();
+        buf ^= 1;
+    }
+    double *Fb = w.F + (size_t)b * d.Mp * d.Tp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                Fb[(size_t)row * d.Tp + t0 + wc * 64 + j * 32 + ln] = (double)acc[i][j][r];
+            }
+}
+
 // ---------------------------------------------------------------------------
 // Parameter tables for one chain, executed by one 256-thread workgroup.
 // Bijector (inference.py:525-535), the rate tables of transition_rate_fn
@@ -435,21 +619,14 @@ inline bool xcd_affinity_applies(int per, int nb) {
 
 // TSM (sampler, GRAD, SRC 1): tile scalars for the chunked leapfrog -- 0 none, 1 column scalars,
 // 2 column and row scalars (Work::TS); compile-time so that the plain kernel carries none of it.
-template <bool GRAD, int SRC, int TSM = 0>
-__global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
+template <bool GRAD, int SRC, int TSM>
+__device__ __forceinline__ void se_tile(const Dims &d, const Consts &c, const Work &w, int bx, int by, int bz) {
     __shared__ double colbuf[4][WAVE];
     __shared__ double llbuf[4][WAVE], psibuf[4][WAVE];
     __shared__ double rowbuf[GRAD ? 4 * SE_RW * SE_RS : 1];
     __shared__ double rlbuf[4][WAVE], rsbuf[4][WAVE];
     __shared__ double2 ltab[LDSTAB_N];
     debug_skew(d);
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (d.aff_nb > 0) {
-        int tile;
-        xcd_affine(blockIdx.x, d.ntc * d.nmt, d.aff_nb, bz, tile);
-        bx = tile % d.ntc;
-        by = tile / d.ntc;
-    }
     const int b = d.b0 + bz, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = bx * WAVE + lane;
     const int m0 = by * SE_TM + wave * SE_RW;
@@ -556,6 +733,56 @@ __global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
             if (lane == 0) { w.TS[tile * 4 + 2] = rl; w.TS[tile * 4 + 3] = rs; }
         }
     }
+}
+
+template <bool GRAD, int SRC, int TSM = 0>
+__global__ __launch_bounds__(256) void k_se(Dims d, Consts c, Work w) {
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (d.aff_nb > 0) {
+        int tile;
+        xcd_affine(blockIdx.x, d.ntc * d.nmt, d.aff_nb, bz, tile);
+        bx = tile % d.ntc;
+        by = tile / d.ntc;
+    }
+    se_tile<GRAD, SRC, TSM>(d, c, w, bx, by, bz);
+}
+
+// Stateless evaluation: the S->E tiles and, in the same launch, the fold of k_scan's per-day I->R
+// partials (k_colreduce's blocks: they only feed k_finish) -- 1-D grid of n_se + ntc * nb blocks.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_se_colreduce(Dims d, Consts c, Work w, int nb) {
+    const int n_se = d.ntc * d.nmt * nb;
+    int L = blockIdx.x;
+    if (L >= n_se) {
+        L -= n_se;
+        colreduce_block(d, w, L % d.ntc, L / d.ntc);
+        return;
+    }
+    int bx, by, bz;
+    if (d.aff_nb > 0) {
+        int tile;
+        xcd_affine(L, d.ntc * d.nmt, d.aff_nb, bz, tile);
+        bx = tile % d.ntc;
+        by = tile / d.ntc;
+    } else {
+        bx = L % d.ntc;
+        by = (L / d.ntc) % d.nmt;
+        bz = L / (d.ntc * d.nmt);
+    }
+    se_tile<GRAD, 0, 0>(d, c, w, bx, by, bz);
+}
+
+// k_scan<0> and, as one more block per chain, the parameter tables (k_params: it depends on u only)
+__global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan_params(Dims d, Consts c, Work w, const double *__restrict__ events,
+                                                                   const double *__restrict__ u_all) {
+    if ((int)blockIdx.x == d.nrb_scan) {
+        __shared__ double sh[4];
+        __shared__ double seg[256];
+        if (threadIdx.x >= 256) return;                     // param_tables is written for 256 threads
+        param_tables(d, c, w, d.b0 + blockIdx.y, u_all + (size_t)(d.b0 + blockIdx.y) * d.P, seg, sh);
+        return;
+    }
+    scan_rows<0>(d, c, w, events);
 }
 
 // ---------------------------------------------------------------------------

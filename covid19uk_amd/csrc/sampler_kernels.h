@@ -305,10 +305,11 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         }
     }
     // constants of phase 3 (CAR precision rows in ELL form): fetched now, used after the leapfrog
-    constexpr int QPRE = 8;
+    // (not at HM = 4, M > 1024: 96 more registers per lane there, and the instance spilled 113-161 of them)
+    constexpr int QPRE = HM <= 2 ? 8 : 1;
     double qell_v[HM][QPRE];
     int qell_c[HM][QPRE];
-    const bool ell_pre = c.qw > 0 && c.qw <= QPRE;
+    const bool ell_pre = HM <= 2 && c.qw > 0 && c.qw <= QPRE;
 #pragma unroll
     for (int k = 0; k < HM; ++k) {
         const int m = tid + k * HB;

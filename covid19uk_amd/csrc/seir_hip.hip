@@ -53,6 +53,8 @@ struct seir_ctx {
     double *last_logp = nullptr, *last_grad = nullptr;
     bool prepared = false;
     int opt_skew = 0, opt_affinity = 3;     // seir_set_option
+    int opt_gemm_f32 = 0;
+    std::vector<float> cstar32_host;        // fp32 copy of the padded Cstar, uploaded when the option is first set
 };
 
 static inline int ceil_to(int x, int q) { return (x + q - 1) / q * q; }
@@ -176,6 +178,11 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
     }
     int rc;
     if ((rc = dev_upload(ctx, &ctx->c.logtab, ltab))) return rc;
+    {
+        std::vector<double> lfb(SCAN_LFT);
+        for (int i = 0; i < SCAN_LFT; ++i) lfb[i] = std::lgamma((double)i + 1.0);
+        if ((rc = dev_upload(ctx, &ctx->c.lfact_big, lfb))) return rc;
+    }
     {   // ELL copy of car_Q (adjacency rows are short): [k][m] so that a wave reads coalesced
         int qw = 0;
         for (int m = 0; m < M; ++m) qw = std::max(qw, qrow[m + 1] - qrow[m]);
@@ -195,6 +202,7 @@ static int create_impl(const seir_desc *ds, seir_ctx *ctx) {
         }
     }
     if ((rc = dev_upload(ctx, &ctx->c.Cstar, Cs))) return rc;
+    ctx->cstar32_host.assign(Cs.begin(), Cs.end());             // rounded to fp32; goes to the device only if asked for
     if ((rc = dev_upload(ctx, &ctx->c.N, N))) return rc;
     if ((rc = dev_upload(ctx, &ctx->c.invN, invN))) return rc;
     if ((rc = dev_upload(ctx, &ctx->c.la, la))) return rc;
@@ -284,6 +292,21 @@ extern "C" int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value) {
             if (value < 0 || value > 3) return fail(SEIR_ERR_INVALID, "xcd affinity is a 2-bit mask");
             ctx->opt_affinity = value;
             return 0;
+        case SEIR_OPT_GEMM_F32: {
+            if (value < 0 || value > 1) return fail(SEIR_ERR_INVALID, "gemm_f32 is 0 or 1");
+            if (value && !ctx->c.Cstar32) {
+                HIP_TRY(hipSetDevice(ctx->device));
+                int rc = dev_upload(ctx, &ctx->c.Cstar32, ctx->cstar32_host);
+                if (rc) return rc;
+                if ((rc = dev_alloc(ctx, &ctx->w.Xn32, (size_t)ctx->Bmax * ctx->d.Mp * ctx->d.Tp))) return rc;
+            }
+            if (value && (ctx->d.Mp % GF_T != 0 || ctx->d.Tp % GF_T != 0))
+                return fail(SEIR_ERR_INVALID, "the fp32 contraction needs ceil64(M) and ceil64(T) to be multiples of %d (M=%d, T=%d)",
+                            GF_T, ctx->d.M, ctx->d.T);
+            ctx->opt_gemm_f32 = value;
+            ctx->prepared = false;
+            return 0;
+        }
         default:
             return fail(SEIR_ERR_INVALID, "unknown option %d", option);
     }
@@ -292,7 +315,7 @@ extern "C" int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value) {
 template <int SRC>
 static void launch_scan(seir_ctx *ctx, const LaunchCfg &l, const double *events) {
     const Dims &d = l.d;
-    const size_t lds = (size_t)SCAN_WAVES * d.Tp * 2 * sizeof(double);
+    const size_t lds = ((size_t)SCAN_WAVES * d.Tp * 2 + SCAN_LFT) * sizeof(double);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_scan<SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_scan<SRC>, dim3(d.nrb_scan, l.nb), dim3(SCAN_WAVES * WAVE), lds,
@@ -313,13 +336,30 @@ static void launch_gemm_t(seir_ctx *ctx, const LaunchCfg &l) {
     hipLaunchKernelGGL((k_gemm<TN>), dim3(d.Tp / TN, d.Mp / GEMM_TM, l.nb), dim3(gemm_threads<TN>()), lds, l.st, d, ctx->c,
                        ctx->w);
 }
+#ifndef GEMM_NCG
+#define GEMM_NCG 3
+#endif
 static void launch_gemm(seir_ctx *ctx, const LaunchCfg &l) {
+    if (ctx->opt_gemm_f32 && ctx->c.Cstar32 && ctx->w.Xn32 && l.d.Mp % GF_T == 0 && l.d.Tp % GF_T == 0) {
+        hipLaunchKernelGGL(k_gemm_f32, dim3(l.d.Tp / GF_T, l.d.Mp / GF_T, l.nb), dim3(256), 0, l.st, l.d, ctx->c, ctx->w);
+        return;
+    }
     // 64 x 96 tiles only where they turn two rounds of workgroups into one (UK-380, 8 chains: 288 -> 192 on
     // 256 CUs, 34.6 -> 32.9 us); on large grids the 6-wave tile loses to the 4-wave one (SYN-2048: 38.6 vs 51.7 TF)
     const Dims &d = l.d;
     const long t64 = (long)(d.Tp / 64) * (d.Mp / GEMM_TM) * l.nb, t96 = (long)(d.Tp / 96) * (d.Mp / GEMM_TM) * l.nb;
-    if (d.Tp % 96 == 0 && t64 > 256 && t96 <= 256) launch_gemm_t<96>(ctx, l);
-    else launch_gemm_t<64>(ctx, l);
+    if (d.Tp % 96 == 0 && t64 > 256 && t96 <= 256) {
+        // the eight-wave form of the 64 x 96 tile: every SIMD of a CU carries two waves (k_gemm<96>'s six waves: 2,2,1,1)
+        const size_t lds = gemm_lds_bytes<96>();
+        static bool attr_set = false;
+        if (!attr_set && lds > 64 * 1024) {
+            (void)hipFuncSetAttribute((const void *)k_gemm_w8<GEMM_NCG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_gemm_w8<GEMM_NCG>, dim3(d.Tp / 96, d.Mp / GEMM_TM, l.nb), dim3(256 * GEMM_NCG), lds, l.st, d, ctx->c, ctx->w);
+    } else {
+        launch_gemm_t<64>(ctx, l);
+    }
 }
 static void launch_params(seir_ctx *ctx, const LaunchCfg &l, const double *u) {
     hipLaunchKernelGGL(k_params, dim3(l.nb), dim3(256), 0, l.st, l.d, ctx->c, ctx->w, u);
@@ -374,11 +414,33 @@ extern "C" int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_
     return 0;
 }
 
+// The full evaluation in four launches: [state scan | parameter tables], mobility contraction,
+// [S->E tiles | fold of the scan's I->R partials], reduction -- the tables depend on u only and the fold
+// feeds the last launch only, so each rides along with the wide kernel next to it.
 extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, const double *events_dev,
                                  double *logp_dev, double *grad_dev) {
-    int rc = seir_prepare_events_dev(ctx, B, events_dev);
+    int rc = check_batch(ctx, B);
     if (rc) return rc;
-    return seir_eval_prepared_dev(ctx, B, u_dev, logp_dev, grad_dev);
+    if (!events_dev || !u_dev || !logp_dev) return fail(SEIR_ERR_INVALID, "null u/events/logp pointer");
+    const LaunchCfg l = whole(ctx, B);
+    Dims d = l.d;
+    const size_t lds = ((size_t)SCAN_WAVES * d.Tp * 2 + SCAN_LFT) * sizeof(double);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_scan_params, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_scan_params, dim3(d.nrb_scan + 1, B), dim3(SCAN_WAVES * WAVE), lds, l.st, d, ctx->c, ctx->w,
+                       events_dev, u_dev);
+    launch_gemm(ctx, l);
+    const bool affinity = (l.affinity & 1) && xcd_affinity_applies(d.ntc * d.nmt, B) && (d.ntc * B) % 8 == 0;
+    d.aff_nb = affinity ? B : 0;
+    const dim3 grid((unsigned)(d.ntc * d.nmt * B + d.ntc * B));
+    if (grad_dev) hipLaunchKernelGGL(k_se_colreduce<true>, grid, dim3(256), 0, l.st, d, ctx->c, ctx->w, B);
+    else hipLaunchKernelGGL(k_se_colreduce<false>, grid, dim3(256), 0, l.st, d, ctx->c, ctx->w, B);
+    launch_finish(ctx, l, u_dev, logp_dev, grad_dev);
+    HIP_TRY(hipGetLastError());
+    ctx->last_events = events_dev;
+    ctx->prepared = true;
+    ctx->last_u = u_dev; ctx->last_logp = logp_dev; ctx->last_grad = grad_dev;
+    return 0;
 }
 
 static int host_eval(seir_ctx *ctx, int B, const double *u, const double *events, double *logp, double *grad) {

@@ -129,9 +129,12 @@ class SeirModel:
     def sync(self):
         _lib.check(self._lib.seir_sync(self._ctx))
 
-    def set_option(self, debug_skew=None, xcd_affinity=None):
+    def set_option(self, debug_skew=None, xcd_affinity=None, gemm_f32=None):
         """Launch options of the context (seir_set_option): the workgroup-timing test hook and the
-        chain <-> XCD block mapping.  Neither changes a result."""
+        chain <-> XCD block mapping (neither changes a result), and `gemm_f32`: the mobility contraction
+        with fp32 operands on the fp32 matrix instruction (BASELINE config 5; ~1e-8 relative on the log-prob)."""
+        if gemm_f32 is not None:
+            _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_GEMM_F32, int(bool(gemm_f32))))
         if debug_skew is not None:
             _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_DEBUG_SKEW, int(debug_skew)))
         if xcd_affinity is not None:

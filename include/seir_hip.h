@@ -101,13 +101,18 @@ int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_dev,
 int seir_sync(seir_ctx *ctx);
 void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context */
 
-/* Launch options of a context (no reference counterpart; nothing here changes a result):
+/* Launch options of a context (no reference counterpart; the first two do not change a result):
  *   SEIR_OPT_DEBUG_SKEW      0 off; 1..3: test hook, a pseudo-random third of the workgroups of every
  *                            launch starts ~30 us late (results must not depend on workgroup timing)
  *   SEIR_OPT_XCD_AFFINITY    bit 0 gradient kernel, bit 1 event-update kernels: chain <-> XCD affine block
  *                            mapping (default 3); speed only
+ *   SEIR_OPT_GEMM_F32        1: the mobility contraction F = Cstar . I/N (model_spec.py:262 for all days) with fp32
+ *                            operands on v_mfma_f32_32x32x2_f32 instead of the fp64 matrix instruction (BASELINE
+ *                            config 5).  THIS ONE CHANGES RESULTS: F carries ~1e-7 relative error, the log-prob
+ *                            ~1e-8 -- outside the 1e-9 the fp64 path is held to; off by default.  Needs
+ *                            ceil64(M) and ceil64(T) to be multiples of 128.
  * Options are read when a launch is enqueued (for a sampler using graph replay: at capture). */
-enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1 };
+enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2 };
 int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value);
 
 /* Device memory helpers so that a ctypes host can keep inputs resident

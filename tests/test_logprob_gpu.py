@@ -235,3 +235,41 @@ def test_syn2048_matches_c_oracle(Model):
         assert abs(lp[b] - want) <= RTOL_LOGP * abs(want), (lp[b], want)
         scale = np.maximum(np.abs(gw), 1e-6 * np.abs(gw).max())
         assert np.max(np.abs(g[b] - gw) / scale) < RTOL_GRAD
+
+
+def test_fp32_mfma_contraction_at_syn2048(Model):
+    """BASELINE config 5 ("fp32 MFMA mobility matvec", 2048 regions x 730 days): the contraction F = Cstar . I/N
+    with fp32 operands on v_mfma_f32_32x32x2_f32 (option gemm_f32) against the C oracle.  fp32 products and
+    accumulation put ~1e-7 relative error into F; what reaches the log-prob was measured at 3e-10 .. 1.2e-9,
+    the gradient at 2e-7 of its largest component -- stated here as 1e-8 / 2e-6, outside the 1e-9 / 1e-6
+    of the fp64 path, which is why the option is off by default."""
+    from oracle import c_binding
+    case = H.build_case("syn2048", 14)
+    c_binding.set_threads(8)
+    u, ev = _batch(case, 2, 14)
+    u[:, :6] = case["u"][:6] + 0.01 * np.random.default_rng(14).normal(size=(2, 6))
+    with Model(case["cov"], case["init"], max_chains=2) as model:
+        exact = model.log_prob_grad(u, ev)
+        model.set_option(gemm_f32=True)
+        lp, g = model.log_prob_grad(u, ev)
+        t32 = model.time_kernel("gemm", 2, 5)
+        model.set_option(gemm_f32=False)
+        again = model.log_prob_grad(u, ev)
+        t64 = model.time_kernel("gemm", 2, 5)
+    assert np.array_equal(exact[0], again[0]) and np.array_equal(exact[1], again[1])     # the option switches back cleanly
+    assert not np.array_equal(lp, exact[0])                                            # ... and it did switch
+    for b in range(2):
+        want, gw = c_binding.evaluate(case["k"], u[b], ev[b], 1, want_grad=True)
+        assert abs(lp[b] - want) <= 1e-8 * abs(want), (lp[b], want)
+        assert np.max(np.abs(g[b] - gw)) < 2e-6 * np.abs(gw).max()
+    assert t32 < 0.6 * t64, (t32, t64)
+
+
+def test_fp32_contraction_needs_128_tiles(Model):
+    from covid19uk_amd import _lib
+    case = H.build_case("ni11", 3)
+    with Model(case["cov"], case["init"], max_chains=1) as model:
+        with pytest.raises(_lib.SeirError):
+            model.set_option(gemm_f32=True)          # ceil64(11) = 64 is not a multiple of 128
+        lp = model.log_prob(case["u"], case["events"])
+        assert abs(lp - so.joint_log_prob(case["u"], case["events"], case["k"], "stable")) <= RTOL_LOGP * abs(lp)
