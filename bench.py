@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--chains-per-gpu", type=int, default=8)
     ap.add_argument("--adapt-sweeps", type=int, default=60, help="untimed dual-averaging sweeps during setup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-egress", action="store_true",
+                    help="skip the overlapped-egress measurement (kernel profiles: concurrent copies stretch kernel durations)")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end (HDF5-writing) single-chain measurement")
     ap.add_argument("--no-chains-scaling", action="store_true",
                     help="skip the extra (untimed-by-the-contract) runs at 32 and 64 chains on this GPU")
@@ -184,10 +186,12 @@ def main():
     # page-locked memory on a copy stream while the next one runs (ChainSampler.sample_bursts; what the CLI does)
     n_bursts = max(16, K // burst)
     touched = []
-    sampler.sample_bursts(2, burst, lambda tr_, i: None)          # untimed: page-locks the two host buffers
-    t2 = time.perf_counter()
-    sampler.sample_bursts(n_bursts, burst, lambda tr_, i: touched.append(int(tr_.events[-1, 0, 0, 0, 0])))
-    overlapped = time.perf_counter() - t2
+    overlapped = None
+    if not a.no_egress:
+        sampler.sample_bursts(2, burst, lambda tr_, i: None)          # untimed: page-locks the two host buffers
+        t2 = time.perf_counter()
+        sampler.sample_bursts(n_bursts, burst, lambda tr_, i: touched.append(int(tr_.events[-1, 0, 0, 0, 0])))
+        overlapped = time.perf_counter() - t2
 
     # dominant kernel of the sweep: the gradient kernel (17 launches per sweep)
     grad_ms = sampler.time_grad_kernel(200)
@@ -344,7 +348,7 @@ def main():
             "spinup_sweeps": spin_sweeps,
             "log_prob_evals_per_sec": evals,
             "hip_event_ms_per_step": ev_ms / K,
-            "pcie_inclusive_samples_per_sec": world * B * n_bursts * burst / overlapped,
+            "pcie_inclusive_samples_per_sec": (world * B * n_bursts * burst / overlapped) if overlapped else None,
             "pcie_inclusive_note": f"{n_bursts} bursts of {burst} sweeps, draws (theta, events int32, kernel results) copied to "
                                    "page-locked host memory on a copy stream while the next burst runs",
             "pcie_serial_samples_per_sec": world * B * K / (elapsed + d2h),

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 out=gpurun_out/${tag}
 rm -rf "$out"; mkdir -p "$out"
 python3 bench.py --steps 200 --warmup 20 > "$out/bench.json" 2> "$out/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o k -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-chains-scaling \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o k -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-chains-scaling --no-cli --no-egress \
     > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -o k -- python3 tools/quick_sweep_bench.py --groups 1 --sweeps 20 \
