@@ -77,6 +77,7 @@ _SIGNATURES = {
     "seir_create": (ctypes.c_int, [ctypes.POINTER(SeirDesc), c_void_pp]),
     "seir_destroy": (None, [ctypes.c_void_p]),
     "seir_num_params": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_set_initial_state": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "seir_log_prob": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
     "seir_log_prob_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_double_p, c_double_p,
                                           c_double_p, c_double_p]),

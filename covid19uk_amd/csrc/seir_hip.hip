@@ -263,6 +263,20 @@ extern "C" int seir_create(const seir_desc *ds, seir_ctx **out) {
 
 extern "C" int seir_num_params(const seir_ctx *ctx) { return ctx ? ctx->d.P : SEIR_ERR_INVALID; }
 
+extern "C" int seir_set_initial_state(seir_ctx *ctx, const double *init_state) {
+    if (!ctx || !init_state) return fail(SEIR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int M = ctx->d.M;
+    for (int i = 0; i < 4 * M; ++i)
+        if (!(init_state[i] >= 0.0) || init_state[i] != std::floor(init_state[i]))
+            return fail(SEIR_ERR_INVALID, "init_state[%d]=%g is not a non-negative integer count", i, init_state[i]);
+    // the padded rows [M, Mp) stay zero; blocking copy: the caller's buffer is not retained
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(const_cast<double *>(ctx->c.init), init_state, sizeof(double) * 4 * M, hipMemcpyHostToDevice));
+    ctx->prepared = false;
+    return 0;
+}
+
 static int check_batch(seir_ctx *ctx, int B) {
     if (!ctx) return fail(SEIR_ERR_INVALID, "null context");
     if (B < 1 || B > ctx->Bmax) return fail(SEIR_ERR_INVALID, "B=%d outside [1, max_chains=%d]", B, ctx->Bmax);

@@ -22,10 +22,14 @@ def _dptr(a: np.ndarray):
 
 
 class SeirModel:
-    def __init__(self, covariates: ms.Covariates, initial_state, max_chains: int = 1, device: int = 0):
+    def __init__(self, covariates: ms.Covariates, initial_state, max_chains: int = 1, device: int = 0,
+                 constants: ms.DerivedConstants = None):
+        """`constants`: pre-derived closure constants to use instead of `derive_constants(covariates)` -- a
+        T-shard passes the slices of the FULL series' constants (the weekday is centred over all days,
+        model_spec.py:224-225), see covid19uk_amd/tshard.py."""
         self._lib = _lib.load()
         self._ctx = ctypes.c_void_p()
-        k = ms.derive_constants(covariates)
+        k = ms.derive_constants(covariates) if constants is None else constants
         self.M, self.T = covariates.M, covariates.T
         self.P = ms.num_params(self.M, self.T)
         self.max_chains = int(max_chains)
@@ -45,6 +49,14 @@ class SeirModel:
             nu=ms.NU, time_delta=ms.TIME_DELTA, rate_floor=ms.RATE_FLOOR)
         _lib.check(self._lib.seir_create(ctypes.byref(desc), ctypes.byref(self._ctx)))
         assert self._lib.seir_num_params(self._ctx) == self.P
+
+    def set_initial_state(self, initial_state):
+        """Replace S,E,I,R at the first day (seir_set_initial_state)."""
+        init = np.ascontiguousarray(initial_state, dtype=np.float64)
+        if init.shape != (self.M, 4):
+            raise ValueError(f"initial_state must be [M,4]=({self.M},4), got {init.shape}")
+        _lib.check(self._lib.seir_set_initial_state(self._ctx, _dptr(init)))
+        self.initial_state = init
 
     # -- lifetime -----------------------------------------------------------
     def close(self):

@@ -75,6 +75,12 @@ int seir_create(const seir_desc *desc, seir_ctx **out);
 void seir_destroy(seir_ctx *ctx);
 int seir_num_params(const seir_ctx *ctx);          /* P */
 
+/* Replace the initial state S,E,I,R [M*4] of the context (CovidUK's `initial_state`, model_spec.py:139;
+ * inference.py:511).  Host pointer; ordered on the context stream.  Used by the T-sharded evaluation
+ * (SURVEY.md 8e): a shard's state at its first day follows from the events of the shards before it.
+ * With a sampler attached, call seir_sampler_set_state / _refresh afterwards. */
+int seir_set_initial_state(seir_ctx *ctx, const double *init_state);
+
 /* joint_log_prob(unconstrained_params, events) for a batch of B chains
  * (inference.py:537-557).  Host pointers; blocking. */
 int seir_log_prob(seir_ctx *ctx, int32_t B, const double *u, const double *events,
