@@ -803,7 +803,13 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
 #endif
     // a speculative role's phases (slots 8..11): role SEIR_STAMP_ROLE of chain 0 in the launch whose S->E slot matches
     const bool rstamp_on = role == SEIR_STAMP_ROLE && b == 0 && se.slot == (SEIR_STAMP_SLOT & 2) && se.scan == 0;
+#ifdef SEIR_STAMP_PROPOSE      // phases inside the speculative role's mv_propose (slots 4..9); its own phases move to 12..15
+#define RSTAMP(i) do { if (threadIdx.x == 0 && rstamp_on) ((unsigned long long *)(stamp_hs + 16))[(i) + 4] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#undef PSTAMP
+#define PSTAMP(i) do {} while (0)
+#else
 #define RSTAMP(i) do { if (threadIdx.x == 0 && rstamp_on) ((unsigned long long *)(stamp_hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #else
 #define PSTAMP(i) do {} while (0)
 #define RSTAMP(i) do {} while (0)
@@ -883,6 +889,9 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         // of this pair, role 2: S->E-type of the next pair)
         const Move *fix = (pend_acc && pendp->tgt == mine.tgt) ? pendp : nullptr;
         RSTAMP(9);
+#if defined(SEIR_STAMPS) && defined(SEIR_STAMP_PROPOSE)
+        L.stamp_hs = stamp_hs; L.stamp_on = rstamp_on;
+#endif
         mv_rows_to_lds(d, w, s, b, mine, pre_ok, pre_nx, fix, L, rtl);
         mv_propose(d, w, s, ch, b, mine, sm_nx, L, ltab);
         RSTAMP(10);

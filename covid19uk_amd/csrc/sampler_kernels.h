@@ -1032,22 +1032,9 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
         const int j = mv.m[i0];
         if (j < r_lo || j >= r_hi) continue;
         const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
-        double coef[MMAX];
-#pragma unroll
-        for (int i = 0; i < MMAX; ++i)
-            coef[i] = (i < mv.n && mv.tgt == 1)
-                          ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
-                          : 0.0;
-        double cfp[MMAX];
-#pragma unroll
-        for (int i = 0; i < MMAX; ++i)
-            cfp[i] = (fp && i < fp->n) ? c.Cstar[(size_t)fp->m[i] * d.Kp0 + j] * c.invN[fp->m[i]] * (double)(-fp->dsrc[i])
-                                       : 0.0;
         {
-            double dF = 0.0;
-#pragma unroll
-            for (int i = 0; i < MMAX; ++i)
-                if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+            // which cells can change at all is known from the descriptor alone; every load of a touched cell --
+            // the mobility coefficients of the F shift as well as the planes -- is then issued in ONE batch
             const bool in_state = t > mv.lo[i0] && t <= mv.hi[i0];
             int dS = 0, dE = 0, dI = 0, dkt = 0;
             if (in_state) {
@@ -1056,7 +1043,27 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
             }
             if (t == mv.a[i0]) dkt += mv.dka[i0];
             if (t == mv.b[i0]) dkt += mv.dkb[i0];
-            if (dS == 0 && dE == 0 && dI == 0 && dkt == 0 && dF == 0.0) continue;
+            bool f_moves = false;
+            if (mv.tgt == 1) {
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i) f_moves |= (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]);
+            }
+            if (dS == 0 && dE == 0 && dI == 0 && dkt == 0 && !f_moves) continue;
+            double coef[MMAX];
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                coef[i] = (i < mv.n && mv.tgt == 1)
+                              ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                              : 0.0;
+            double cfp[MMAX];
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                cfp[i] = (fp && i < fp->n) ? c.Cstar[(size_t)fp->m[i] * d.Kp0 + j] * c.invN[fp->m[i]] * (double)(-fp->dsrc[i])
+                                           : 0.0;
+            double dF = 0.0;
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
             const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
             const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
             const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
@@ -1197,8 +1204,13 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_move_delta(Dims d, Consts c, 
 #define SEIR_STAMP_BLOCK 0
 #endif
     double *dst_hs = ch.hs + (size_t)b * NHS;
+#ifdef SEIR_STAMP_PROPOSE
+#define DSTAMP(i) do {} while (0)
+    bool dstamp_on = false;
+#else
 #define DSTAMP(i) do { if (threadIdx.x == 0 && b == 0 && bx == SEIR_STAMP_BLOCK && dstamp_on) ((unsigned long long *)(dst_hs + 16))[12 + i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     bool dstamp_on = true;
+#endif
 #else
 #define DSTAMP(i) do {} while (0)
 #endif
