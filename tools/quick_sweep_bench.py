@@ -11,7 +11,7 @@ def main():
     ap.add_argument("--chains", type=int, default=8)
     ap.add_argument("--sweeps", type=int, default=100)
     ap.add_argument("--groups", default="1,2,4,8")
-    ap.add_argument("--hmc", default="fused")
+    ap.add_argument("--hmc", default="chunk")
     ap.add_argument("--moves", default="paired")
     args = ap.parse_args()
     import __graft_entry__ as entry
