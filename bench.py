@@ -67,19 +67,32 @@ def cpu_baseline(cov, init, events, u0, n_sweeps, seed, cores=None):
     if cores is None:
         cores = min(len(os.sched_getaffinity(0)), 16)
     c_binding.set_threads(cores)
-    lp = lambda u, ev: c_binding.evaluate(k, u, ev, 1)                      # noqa: E731
-    lpg = lambda u, ev: c_binding.evaluate(k, u, ev, 1, want_grad=True)     # noqa: E731
+    in_c = [0.0]
+
+    def lp(u, ev):
+        t = time.perf_counter()
+        r = c_binding.evaluate(k, u, ev, 1)
+        in_c[0] += time.perf_counter() - t
+        return r
+
+    def lpg(u, ev):
+        t = time.perf_counter()
+        r = c_binding.evaluate(k, u, ev, 1, want_grad=True)
+        in_c[0] += time.perf_counter() - t
+        return r
     ch = mo.OracleChain(k, MCMC_CONFIG, u0, events, seed=seed, chain_id=0, log_prob_fn=lp, log_prob_grad_fn=lpg)
     ch.eps = 2e-5
     t0 = time.perf_counter()
     ch.sweep_once()
     one = time.perf_counter() - t0
     n = n_sweeps if n_sweeps > 0 else max(2, min(40, int(10.0 / max(one, 1e-3))))
+    in_c[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(n):
         ch.sweep_once()
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "posterior samples/sec", "cores": cores, "kind": "port",
+            "density_share": in_c[0] / dt,      # fraction of the time inside the C density (the rest: NumPy proposal logic)
             "sample": f"{n} sweeps of 1 chain, oracle/mcmc_oracle.py + oracle/seir_oracle.c (OpenMP, "
                       f"{cores} threads), {ch.n_evals} full log-prob evaluations, same workload"}
 

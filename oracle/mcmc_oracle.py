@@ -194,7 +194,11 @@ class OracleChain:
 
     # -- event moves ---------------------------------------------------------
     def _closed_state(self):
-        return so.compute_state(self.k.initial_state, self.events, closed=True)   # [M,T+1,4]
+        # [M,T+1,4]; recomputed only when the event tensor has changed (an accepted update replaces self.events)
+        if getattr(self, "_st_for", None) is not self.events:
+            self._st = so.compute_state(self.k.initial_state, self.events, closed=True)
+            self._st_for = self.events
+        return self._st
 
     def _mh(self, new_events, valid, logq, logu):
         if valid:
