@@ -145,7 +145,7 @@ def main():
     model = SeirModel(cov, init, max_chains=B, device=local)
     burst = max(1, min(K, 50))                    # sweeps per burst of the overlapped-egress measurement
     sampler = ChainSampler(model, MCMC_CONFIG, B, seed=a.seed, first_chain_id=first_chain,
-                           trace_capacity=max(K, 2 * burst), record_events=True)
+                           trace_capacity=max(K, 2 * burst), record_events="u16")
     sampler.set_state(u0, ev0)
     sampler.set_kernel(step_size=2e-5)
     # setup (untimed): a short dual-averaging window, then pool the step size over ALL chains
@@ -284,7 +284,7 @@ def main():
             ux = synth.jitter_params(u_true, Bx, scale=0.002, seed=7, T=cov.T)
             mx = SeirModel(cov, init, max_chains=Bx, device=local)
             sx = ChainSampler(mx, MCMC_CONFIG, Bx, seed=a.seed, first_chain_id=0, trace_capacity=40,
-                              record_events=True)
+                              record_events="u16")
             sx.set_state(ux, np.stack([events] * Bx))
             sx.set_kernel(step_size=pooled)
             sx.run(10)
@@ -309,7 +309,7 @@ def main():
         import tempfile
         from covid19uk_amd.inference import inference as inf
         m1 = SeirModel(cov, init, max_chains=1, device=local)
-        s1 = ChainSampler(m1, MCMC_CONFIG, 1, seed=a.seed, trace_capacity=100, record_events=True)
+        s1 = ChainSampler(m1, MCMC_CONFIG, 1, seed=a.seed, trace_capacity=100, record_events="u16")
         s1.set_state(u_all[:1], ev0[:1])
         s1.set_kernel(step_size=pooled)
         nbc, nsc = 6, 50
@@ -346,7 +346,7 @@ def main():
             "config": {"workload": f"{a.workload}: M={M} LADs x T={T} days, P={P} parameters",
                        "chains_per_gpu": B, "chains_total": world * B,
                        "sweep": "HMC(16 leapfrogs) + 5 x [S->E move, E->I move, S->E occult, E->I occult]",
-                       "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] + kernel results per sweep",
+                       "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] (uint16 counts) + kernel results per sweep",
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"kernel": "k_se<GRAD=true,SRC=planes> (S->E term + gradient sums, all chains)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -362,7 +362,7 @@ def main():
             "log_prob_evals_per_sec": evals,
             "hip_event_ms_per_step": ev_ms / K,
             "pcie_inclusive_samples_per_sec": (world * B * n_bursts * burst / overlapped) if overlapped else None,
-            "pcie_inclusive_note": f"{n_bursts} bursts of {burst} sweeps, draws (theta, events int32, kernel results) copied to "
+            "pcie_inclusive_note": f"{n_bursts} bursts of {burst} sweeps, draws (theta, events uint16, kernel results) copied to "
                                    "page-locked host memory on a copy stream while the next burst runs",
             "pcie_serial_samples_per_sec": world * B * K / (elapsed + d2h),
             "acceptance": acc, "step_size": pooled, "all_log_probs_finite": finite,

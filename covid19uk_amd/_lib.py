@@ -116,13 +116,13 @@ _SIGNATURES = {
     "seir_sampler_reset_trace": (ctypes.c_int, [ctypes.c_void_p]),
     "seir_sampler_reset_trace_at": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "seir_sampler_read_trace_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_double_p,
-                                                     ctypes.POINTER(ctypes.c_int32), c_double_p, c_double_p]),
+                                                     ctypes.c_void_p, c_double_p, c_double_p]),
     "seir_sampler_trace_wait": (ctypes.c_int, [ctypes.c_void_p]),
     "seir_host_alloc": (ctypes.c_int, [c_void_pp, ctypes.c_uint64]),
     "seir_host_free": (ctypes.c_int, [ctypes.c_void_p]),
     "seir_sampler_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "seir_sampler_read_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_double_p,
-                                               ctypes.POINTER(ctypes.c_int32), c_double_p, c_double_p]),
+                                               ctypes.c_void_p, c_double_p, c_double_p]),
     "seir_sampler_time_grad_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.POINTER(ctypes.c_float)]),
     "seir_sampler_pair_timeouts": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),

@@ -47,6 +47,7 @@ struct SamplerCfg {
     double target_accept;
     int cap;          // trace slots
     int nrb_d;        // row blocks of k_move_delta / k_move_pa2
+    int ev16;         // 1: samples/seir recorded as uint16 (half the burst buffer and half the bytes over PCIe)
     int disable_mask; // bit 0 HMC, bits 1..4 the four event sub-kernels: proposal drawn, always rejected
 };
 
@@ -96,7 +97,8 @@ struct Chains {
     unsigned *slot0;                                     // [1] sweep index of trace slot 0
     // traces
     double *tr_theta;                                    // [cap][B][P]
-    int *tr_events;                                      // [cap][B][M][T][3]
+    void *tr_events;                                     // [cap][B][M][T][3] int32, or uint16 when SamplerCfg::ev16
+    unsigned *ev_overflow;                               // [1] set when a count did not fit the 16-bit trace
     double *tr_hmc;                                      // [cap][B][3]  is_accepted, target_log_prob, step_size
     double *tr_mv;                                       // [cap][B][4][NMVTR]
 };
@@ -1311,7 +1313,9 @@ __global__ __launch_bounds__(256) void k_record(Dims d, Consts c, Work w, Sample
         }
     }
     if (slot >= (unsigned)s.cap || m >= d.M) return;
-    int *out = ch.tr_events + (((size_t)slot * s.B + b) * d.M + m) * d.T * 3;
+    const size_t o0 = (((size_t)slot * s.B + b) * d.M + m) * d.T * 3;
+    int *out = (int *)ch.tr_events + o0;
+    unsigned short *out16 = (unsigned short *)ch.tr_events + o0;
     const size_t q0 = ((size_t)b * d.Mp + m) * d.Tp;
     for (int t0 = 0; t0 < d.T; t0 += 4 * WAVE) {
         int k0[4], k1[4], k2[4];
@@ -1326,7 +1330,15 @@ __global__ __launch_bounds__(256) void k_record(Dims d, Consts c, Work w, Sample
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + j * WAVE + lane;
-            if (t < d.T) { out[t * 3 + 0] = k0[j]; out[t * 3 + 1] = k1[j]; out[t * 3 + 2] = k2[j]; }
+            if (t < d.T) {
+                if (s.ev16) {                                   // uniform
+                    if ((unsigned)(k0[j] | k1[j] | k2[j]) > 0xffffu) ch.ev_overflow[0] = 1u;     // reported by the read
+                    out16[t * 3 + 0] = (unsigned short)k0[j]; out16[t * 3 + 1] = (unsigned short)k1[j];
+                    out16[t * 3 + 2] = (unsigned short)k2[j];
+                } else {
+                    out[t * 3 + 0] = k0[j]; out[t * 3 + 1] = k1[j]; out[t * 3 + 2] = k2[j];
+                }
+            }
         }
     }
 }

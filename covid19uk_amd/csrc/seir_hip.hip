@@ -821,6 +821,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         return fail(SEIR_ERR_INVALID, "occult t_range [%d,%d) outside [0,%d)", ds->t_range_lo, ds->t_range_hi, d.T);
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
+    if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
     if (ds->moves_mode < 0 || ds->moves_mode > 2 || ds->hmc_mode < 0 || ds->hmc_mode > 1)
         return fail(SEIR_ERR_INVALID, "moves_mode is 0..2, hmc_mode 0 or 1");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
@@ -838,6 +839,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     c.cap = ds->trace_capacity;
     c.nrb_d = (d.M + 7) / 8;        // row blocks of k_move_delta (4-row blocks measured slower, twice)
     s->record_events = ds->record_events;
+    c.ev16 = ds->record_events == 2 ? 1 : 0;
     // Launch mode of a sweep's ~76 dependent kernels.  Measured on MI355X / ROCm 7.2 (UK-380, 8 chains):
     // stream launches 0.815 ms per sweep, replay of the captured hipGraph 0.872 ms -- the graph
     // executor costs ~0.75 us more per node than the stream path while the host (3-4 us per launch,
@@ -889,7 +891,12 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.Down, (size_t)2 * 2 * B * 2);
     S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
     S_ALLOC(ch.tr_theta, (size_t)c.cap * B * d.P);
-    S_ALLOC(ch.tr_events, s->record_events ? (size_t)c.cap * B * d.M * d.T * 3 : 1);
+    {
+        char *tre = nullptr;                               // bytes: int32 or uint16 per count
+        S_ALLOC(tre, s->record_events ? (size_t)c.cap * B * d.M * d.T * 3 * (c.ev16 ? 2 : 4) : 4);
+        ch.tr_events = tre;
+    }
+    S_ALLOC(ch.ev_overflow, 1);
     S_ALLOC(ch.tr_hmc, (size_t)c.cap * B * 3);
     S_ALLOC(ch.tr_mv, (size_t)c.cap * B * 4 * NMVTR);
     S_ALLOC(s->ev_stage, (size_t)B * d.M * d.T * 3);
@@ -1285,8 +1292,17 @@ extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
     return 0;
 }
 
+// 16-bit event trace: a count that did not fit was truncated on the device -- fail loudly
+static int check_ev_overflow(seir_sampler *s) {
+    if (!s->cfg.ev16) return 0;
+    unsigned flag = 0;
+    HIP_TRY(hipMemcpy(&flag, s->ch.ev_overflow, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) return fail(SEIR_ERR_STATE, "an event count exceeded 65535: record_events=2 (uint16 trace) cannot hold this chain");
+    return 0;
+}
+
 extern "C" int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, double *theta,
-                                       int32_t *events, double *hmc, double *moves) {
+                                       void *events, double *hmc, double *moves) {
     int rc = sampler_check(s);
     if (rc) return rc;
     const Dims &d = s->ctx->d;
@@ -1300,8 +1316,8 @@ extern "C" int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t c
         HIP_TRY(hipMemcpyAsync(theta, s->ch.tr_theta + (size_t)first * B * d.P, sizeof(double) * count * B * d.P,
                                hipMemcpyDeviceToHost, st));
     if (events)
-        HIP_TRY(hipMemcpyAsync(events, s->ch.tr_events + (size_t)first * B * d.M * d.T * 3,
-                               sizeof(int32_t) * count * B * d.M * d.T * 3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(events, (const char *)s->ch.tr_events + (size_t)first * B * d.M * d.T * 3 * (c.ev16 ? 2 : 4),
+                               (size_t)(c.ev16 ? 2 : 4) * count * B * d.M * d.T * 3, hipMemcpyDeviceToHost, st));
     if (hmc)
         HIP_TRY(hipMemcpyAsync(hmc, s->ch.tr_hmc + (size_t)first * B * 3, sizeof(double) * count * B * 3,
                                hipMemcpyDeviceToHost, st));
@@ -1309,11 +1325,11 @@ extern "C" int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t c
         HIP_TRY(hipMemcpyAsync(moves, s->ch.tr_mv + (size_t)first * B * 4 * NMVTR,
                                sizeof(double) * count * B * 4 * NMVTR, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return 0;
+    return check_ev_overflow(s);
 }
 
 extern "C" int seir_sampler_read_trace_async(seir_sampler *s, int32_t first, int32_t count, double *theta,
-                                             int32_t *events, double *hmc, double *moves) {
+                                             void *events, double *hmc, double *moves) {
     int rc = sampler_check(s);
     if (rc) return rc;
     const Dims &d = s->ctx->d;
@@ -1331,8 +1347,8 @@ extern "C" int seir_sampler_read_trace_async(seir_sampler *s, int32_t first, int
         HIP_TRY(hipMemcpyAsync(theta, s->ch.tr_theta + (size_t)first * B * d.P, sizeof(double) * count * B * d.P,
                                hipMemcpyDeviceToHost, st));
     if (events)
-        HIP_TRY(hipMemcpyAsync(events, s->ch.tr_events + (size_t)first * B * d.M * d.T * 3,
-                               sizeof(int32_t) * count * B * d.M * d.T * 3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(events, (const char *)s->ch.tr_events + (size_t)first * B * d.M * d.T * 3 * (c.ev16 ? 2 : 4),
+                               (size_t)(c.ev16 ? 2 : 4) * count * B * d.M * d.T * 3, hipMemcpyDeviceToHost, st));
     if (hmc)
         HIP_TRY(hipMemcpyAsync(hmc, s->ch.tr_hmc + (size_t)first * B * 3, sizeof(double) * count * B * 3,
                                hipMemcpyDeviceToHost, st));
@@ -1350,6 +1366,7 @@ extern "C" int seir_sampler_trace_wait(seir_sampler *s) {
     if (s->copy_pending) {
         HIP_TRY(hipEventSynchronize(s->ev_copy));
         s->copy_pending = false;
+        return check_ev_overflow(s);
     }
     return 0;
 }

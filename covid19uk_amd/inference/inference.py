@@ -309,7 +309,7 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool
     model = SeirModel(cov, initial_state, max_chains=B, device=lay["device"])
     sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),
                            num_leapfrog_steps=hmc_kernel_kwargs_default()["num_leapfrog_steps"],
-                           trace_capacity=cap, record_events=True, first_chain_id=lay["first_chain_id"])
+                           trace_capacity=cap, record_events="u16", first_chain_id=lay["first_chain_id"])
     u0 = np.zeros((B, P))                                   # inference.py:563-573
     sampler.set_state(u0, np.stack([events] * B))
     print("Initial logpi:", sampler.log_prob(), flush=True)

@@ -25,7 +25,7 @@ MOVE_KEYS = ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I")   # inferen
 class Trace:
     """Draws and kernel results of `count` sweeps for B chains (leading axes [count, B])."""
     theta: np.ndarray        # [n,B,P] constrained parameter draws
-    events: np.ndarray       # [n,B,M,T,3] int32 (or None)
+    events: np.ndarray       # [n,B,M,T,3] int32 or uint16 (or None)
     hmc: dict                # is_accepted, target_log_prob, step_size  -> [n,B]
     moves: dict              # MOVE_KEYS -> dict(is_accepted [n,B], target_log_prob [n,B], proposed_delta [n,B,4,m])
 
@@ -40,7 +40,7 @@ class PinnedTrace:
         B, P, M, T = sampler.B, sampler.P, sampler.M, sampler.T
         self._ptrs = []
         self.theta = self._alloc((count, B, P), np.float64)
-        self.events = self._alloc((count, B, M, T, 3), np.int32) if (events and sampler.record_events) else None
+        self.events = self._alloc((count, B, M, T, 3), sampler.events_dtype) if (events and sampler.record_events) else None
         self.hmc = self._alloc((count, B, 3), np.float64)
         self.moves = self._alloc((count, B, 4, _lib.MOVE_TRACE), np.float64)
 
@@ -92,14 +92,17 @@ class ChainSampler:
         if t_range is None:                       # inference.py:336-339
             t_range = (max(self.T - 21, 0), self.T)
         self.cap = int(trace_capacity)
+        # record_events: False, True (int32 counts) or "u16" (uint16 counts: half the burst buffer and half the
+        # bytes over PCIe; the read fails loudly if a count exceeds 65535)
         self.record_events = bool(record_events)
+        self.events_dtype = np.uint16 if record_events == "u16" else np.int32
         desc = _lib.SeirSamplerDesc(
             num_chains=self.B, dmax=int(config["dmax"]), nmax=int(config["nmax"]), m=self.mmax,
             occult_nmax=int(config["occult_nmax"]),
             num_event_time_updates=int(config["num_event_time_updates"]),
             t_range_lo=int(t_range[0]), t_range_hi=int(t_range[1]),
             num_leapfrog_steps=int(num_leapfrog_steps), trace_capacity=self.cap,
-            first_chain_id=int(first_chain_id), record_events=int(self.record_events),
+            first_chain_id=int(first_chain_id), record_events=(2 if record_events == "u16" else int(self.record_events)),
             seed=int(seed) & (2 ** 64 - 1),
             moves_mode={"paired": 0, "split": 1, "paired-nopre": 2}[moves], hmc_mode={"chunk": 0, "single": 1}[hmc],
             use_graph=int(bool(use_graph)), chain_groups=int(chain_groups), disable_mask=mask,
@@ -200,12 +203,12 @@ class ChainSampler:
     def read_trace(self, count: int, first: int = 0, events: bool = True) -> Trace:
         n = int(count)
         theta = np.empty((n, self.B, self.P))
-        ev = np.empty((n, self.B, self.M, self.T, 3), dtype=np.int32) if (events and self.record_events) else None
+        ev = np.empty((n, self.B, self.M, self.T, 3), dtype=self.events_dtype) if (events and self.record_events) else None
         hmc = np.empty((n, self.B, 3))
         mv = np.empty((n, self.B, 4, _lib.MOVE_TRACE))
         _lib.check(self._lib.seir_sampler_read_trace(
             self._s, int(first), n, _dptr(theta),
-            None if ev is None else ev.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dptr(hmc), _dptr(mv)))
+            None if ev is None else ev.ctypes.data_as(ctypes.c_void_p), _dptr(hmc), _dptr(mv)))
         return self._as_trace(n, theta, ev, hmc, mv)
 
     def read_trace_async(self, count: int, first: int, into: PinnedTrace):
@@ -216,7 +219,7 @@ class ChainSampler:
             raise ValueError("pinned buffer too small")
         _lib.check(self._lib.seir_sampler_read_trace_async(
             self._s, int(first), n, _dptr(into.theta),
-            None if into.events is None else into.events.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            None if into.events is None else into.events.ctypes.data_as(ctypes.c_void_p),
             _dptr(into.hmc), _dptr(into.moves)))
 
     def trace_wait(self):

@@ -177,7 +177,8 @@ typedef struct {
     int32_t num_leapfrog_steps;     /* 16                                (inference.py:326) */
     int32_t trace_capacity;         /* sweeps the burst buffer holds */
     int32_t first_chain_id;         /* global id of chain 0: selects the RNG stream (multi-GPU sharding) */
-    int32_t record_events;          /* 1: record samples/seir for every draw */
+    int32_t record_events;          /* 0: no samples/seir; 1: int32 counts for every draw; 2: uint16 counts (half the burst
+                                       buffer and half the bytes over PCIe; a count > 65535 makes the read fail) */
     uint64_t seed;
     /* ---- ABI v2: launch form and test hooks; all-zero = the defaults ---------------------------- */
     int32_t moves_mode;             /* 0: paired event-update launches (k_move_pair) with the S->E-type proposal
@@ -232,12 +233,12 @@ int seir_sampler_reset_trace_at(seir_sampler *s, int32_t first_slot);
 int seir_sampler_run(seir_sampler *s, int32_t num_sweeps);
 /* Blocking read of trace slots [first, first+count):
  *   theta  [count][B][P]           constrained draws (param_bijector.inverse, inference.py:375)
- *   events [count][B][M][T][3]     int32 counts (NULL to skip)
+ *   events [count][B][M][T][3]     int32 counts -- uint16 if record_events == 2 -- (NULL to skip)
  *   hmc    [count][B][3]           is_accepted, target_log_prob, step_size (inference.py:255-261)
  *   moves  [count][B][4][SEIR_MOVE_TRACE]  per sub-kernel S->E move, E->I move, S->E occult,
  *          E->I occult of the LAST inner scan (MultiScanKernel returns the last results,
  *          inference.py:262-280) */
-int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, double *theta, int32_t *events,
+int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, double *theta, void *events,
                             double *hmc, double *moves);
 
 /* Overlapped egress of a burst (the reference's per-burst posterior.write_samples, inference.py:453-468,
@@ -247,7 +248,7 @@ int seir_sampler_read_trace(seir_sampler *s, int32_t first, int32_t count, doubl
  * page-locked (seir_host_alloc) -- pageable memory works but serialises.  seir_sampler_trace_wait
  * blocks until the last async read has landed; call it before touching the host buffers and before
  * re-using the trace slots being read. */
-int seir_sampler_read_trace_async(seir_sampler *s, int32_t first, int32_t count, double *theta, int32_t *events,
+int seir_sampler_read_trace_async(seir_sampler *s, int32_t first, int32_t count, double *theta, void *events,
                                   double *hmc, double *moves);
 int seir_sampler_trace_wait(seir_sampler *s);
 /* Page-locked host memory for the calls above. */

@@ -469,3 +469,39 @@ def test_overlapped_bursts_deliver_the_same_draws(api):
     assert np.array_equal(np.concatenate([g[2] for g in got]), ref.events)
     assert np.array_equal(np.concatenate([g[3] for g in got]), ref.hmc["target_log_prob"])
     assert np.array_equal(np.concatenate([g[4] for g in got]), ref.moves["move/E->I"]["proposed_delta"])
+
+
+def test_compact_event_trace_is_lossless_and_guards_its_range(api):
+    """record_events="u16": the same draws with the events recorded as uint16 (half the bytes over PCIe), and a
+    chain whose counts do not fit 16 bits makes the read fail instead of delivering truncated counts."""
+    from covid19uk_amd import _lib
+    SeirModel, ChainSampler = api
+    case = H.build_case("micro_17x70", 9, alpha_t_sd=0.005)
+    B, n = 2, 5
+    u, ev = _start(case, B, 9)
+    out = {}
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        for mode in (True, "u16"):
+            with ChainSampler(model, CFG_SMALL, B, seed=5, trace_capacity=n, record_events=mode) as s:
+                s.set_state(u, ev)
+                s.set_kernel(step_size=0.0004)
+                out[mode] = s.sample(n)
+    assert out["u16"].events.dtype == np.uint16 and out[True].events.dtype == np.int32
+    assert np.array_equal(out["u16"].events, out[True].events)
+    assert np.array_equal(out["u16"].theta, out[True].theta)
+    # counts beyond 65535: populations of millions with a fast epidemic
+    cov = case["cov"]
+    import dataclasses
+    big = dataclasses.replace(cov, N=cov.N * 400.0)
+    init = case["init"].copy()
+    init[:, 0] = big.N - init[:, 1:].sum(1)
+    init[:, 2] += 3.0e5
+    init[:, 0] -= 3.0e5
+    evb = np.zeros_like(case["events"])
+    evb[:, 0, 2] = 7.0e4                              # 70 000 removals on day 0
+    with SeirModel(big, init, max_chains=1) as model:
+        with ChainSampler(model, CFG_SMALL, 1, seed=5, trace_capacity=2, record_events="u16") as s:
+            s.set_state(case["u"][None], evb[None])
+            s.set_kernel(step_size=1e-6)
+            with pytest.raises(_lib.SeirError, match="65535"):
+                s.sample(1)
