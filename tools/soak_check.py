@@ -15,11 +15,14 @@ with SeirModel(case["cov"], case["init"], max_chains=B) as model:
     with ChainSampler(model, cfg, B, seed=123, trace_capacity=100, record_events=False) as s:
         s.set_state(u, ev); s.set_kernel(step_size=2e-5)
         s.set_adaptation(adapt_step_size=True, num_adaptation_steps=300)
-        for it in range(30):
+        for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
             s.reset_trace(); s.run(100); model.sync()
             if it == 2: s.set_adaptation(adapt_step_size=False)
         tr = s.read_trace(100, events=False)
         u1, ev1, lp_run = s.get_state()
+        late = s.pair_timeouts()
+        print("k_move_pair hand-off time-outs per chain:", late)
+        assert not late.any()
         print("hmc acc", tr.hmc["is_accepted"].mean(), "step", tr.hmc["step_size"][-1, 0], {k: float(v["is_accepted"].mean()) for k, v in tr.moves.items()})
         for b in range(B):
             want = H.c_oracle_eval(case["k"], u1[b], ev1[b], stable=1)
