@@ -38,7 +38,7 @@ struct Dims {
     int chunked;            // sampler: k_se also writes the tile scalars of the chunked leapfrog (Work::TS):
                             // 1 = column scalars only (the M-chunks sum the row partials themselves), 2 = all four
     int sp_par;             // which of the two Work::sp / Work::gst buffers holds the current position
-    int skew;               // test hook (SEIR_DEBUG_SKEW = 1..3): a third of the workgroups of every launch starts ~30 us late
+    int skew;               // test hook (seir_set_option SEIR_OPT_DEBUG_SKEW = 1..3): a third of the workgroups of every launch starts ~30 us late
     int aff_nb;             // 0 = natural grids (tile, chain); > 0 = 1-D grids of tiles*aff_nb blocks with chain <-> XCD affinity
     double nu, dt, rate_floor, car_half_logdet;
     double L_ei;            // log(1 - exp(-nu dt))

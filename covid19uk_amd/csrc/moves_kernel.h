@@ -7,7 +7,7 @@
 // in LDS, one scan per row), uniforms are drawn by one lane each and broadcast through LDS, the
 // per-metapopulation scalar work runs on one lane of different waves in parallel, barriers order
 // LDS traffic only.  Semantics, RNG slots and the arithmetic of every term are those of the first
-// implementation (k_move_pa / propose() in sampler_kernels.h), against which it was validated.
+// implementation (retired in round 2; it lives on as oracle/mcmc_oracle.py), against which it was validated.
 //
 // Tried and dropped (r01): running the whole MultiScan phase as ONE persistent launch, one
 // workgroup per chain.  It removes 40 launches per sweep but a single CU cannot carry the E->I

@@ -843,7 +843,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     // Launch mode of a sweep's ~76 dependent kernels.  Measured on MI355X / ROCm 7.2 (UK-380, 8 chains):
     // stream launches 0.815 ms per sweep, replay of the captured hipGraph 0.872 ms -- the graph
     // executor costs ~0.75 us more per node than the stream path while the host (3-4 us per launch,
-    // kernels of ~10 us) stays ahead either way.  Default: stream launches; SEIR_GRAPH=1 selects the graph.
+    // kernels of ~10 us) stays ahead either way.  Default: stream launches; seir_sampler_desc::use_graph selects the graph.
     s->use_graph = ds->use_graph != 0;
     s->pair_debug = ds->debug_pair;
     s->hmc_chunked = ds->hmc_mode == 0;
