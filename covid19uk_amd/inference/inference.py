@@ -276,7 +276,19 @@ def chain_file_name(output_file, chain, total_chains):
     return f"{root}_chain{chain}{ext}"
 
 
-def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool_step_size=False):
+def dispersed_start(P, chain_ids, scale, seed):
+    """Starting points u0[B,P]: the reference's zeros (inference.py:563-573) for global chain 0 and, when
+    scale > 0, N(0, scale^2) perturbations for the others, keyed by the GLOBAL chain id so that a chain's
+    start does not depend on how the job is sharded (over-dispersed starts for R-hat)."""
+    u0 = np.zeros((len(chain_ids), P))
+    if scale > 0:
+        for b, c in enumerate(chain_ids):
+            if c > 0:
+                u0[b] = np.random.default_rng([int(seed), 0x5EED, int(c)]).normal(0.0, scale, size=P)
+    return u0
+
+
+def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool_step_size=False, init_jitter=0.0):
     """Constructs and runs the MCMC (covid19uk/inference/inference.py:473-608).
 
     Multi-GPU: launched as one process per GPU, every rank runs `num_chains` chains with
@@ -310,7 +322,7 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool
     sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),
                            num_leapfrog_steps=hmc_kernel_kwargs_default()["num_leapfrog_steps"],
                            trace_capacity=cap, record_events="u16", first_chain_id=lay["first_chain_id"])
-    u0 = np.zeros((B, P))                                   # inference.py:563-573
+    u0 = dispersed_start(P, [lay["first_chain_id"] + c for c in range(B)], float(init_jitter), seed)
     sampler.set_state(u0, np.stack([events] * B))
     print("Initial logpi:", sampler.log_prob(), flush=True)
 
@@ -350,11 +362,13 @@ def main(argv=None):
     parser.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, 0 outside torchrun)")
     parser.add_argument("--pool-step-size", action="store_true",
                         help="sample with the geometric mean of all chains' adapted HMC step sizes (one all_gather)")
+    parser.add_argument("--init-jitter", type=float, default=0.0,
+                        help="sd of the N(0, sd^2) start of chains 1.. in the unconstrained space (chain 0 starts at 0 as the reference)")
     args = parser.parse_args(argv)
     with open(args.config, "r") as f:
         config = yaml.load(f, Loader=yaml.FullLoader)
     mcmc(args.data_file, args.output, config["Mcmc"], seed=args.seed, num_chains=args.chains, device=args.device,
-         pool_step_size=args.pool_step_size)
+         pool_step_size=args.pool_step_size, init_jitter=args.init_jitter)
 
 
 if __name__ == "__main__":

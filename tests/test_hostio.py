@@ -189,3 +189,13 @@ def test_reads_a_file_with_the_layout_xarray_writes():
     init, events = ms.initial_conditions(cases, cov.N, np.random.default_rng(0))
     assert events.shape == (cov.M, cov.T, 3) and init.shape == (cov.M, 4)
     assert np.array_equal(events[..., 2], cases)
+
+
+def test_dispersed_start_is_keyed_by_global_chain_id():
+    from covid19uk_amd.inference import inference as inf
+    assert not inf.dispersed_start(7, [0, 1, 2], 0.0, seed=3).any()          # the reference's start
+    a = inf.dispersed_start(7, [0, 1, 2, 3], 0.1, seed=3)
+    b = inf.dispersed_start(7, [2, 3], 0.1, seed=3)                           # rank 1 of a 2-chains-per-rank job
+    assert not a[0].any() and a[1:].any(axis=1).all()
+    np.testing.assert_array_equal(a[2:], b)
+    assert not np.array_equal(a[1], inf.dispersed_start(7, [1], 0.1, seed=4)[0])
