@@ -108,6 +108,14 @@ __device__ __forceinline__ void l1me_inv(double r, double &L, double &inv, const
         inv = e / om;
     }
 }
+// The series branch alone, for callers that sort out the rare lanes outside [L1ME_SERIES_MIN, L1ME_SERIES_MAX]
+// themselves (the contraction's epilogue: branch-free cells can be interleaved, and the libm branch costs ~40
+// registers wherever it is inlined)
+__device__ __forceinline__ void l1me_inv_series(double r, double &L, double &inv, const double2 *tab) {
+    const double r2 = r * r, ri = fast_rcp(r);
+    L = fast_log(r, tab) + r * (-0.5 + r * (4.1666666666666664e-2 - r2 * (3.4722222222222224e-4 - r2 * (5.5114638447971785e-6 - r2 * 1.0333994708994709e-7))));
+    inv = ri - 0.5 + r * (8.3333333333333329e-2 - r2 * (1.3888888888888889e-3 - r2 * (3.3068783068783071e-5 - r2 * 8.2671957671957672e-7)));
+}
 // The same pair for rates that are not small: the I->R rate exp(gamma0 + gamma1 wd) is ~0.25-0.5 per
 // day, beyond the 4-term range above, and the libm branch (exp, log, divide: ~400 instructions) would be
 // taken by every lane of the single-wave HMC kernels.  8 Bernoulli terms reach r <= 3/4 at < 1e-16:

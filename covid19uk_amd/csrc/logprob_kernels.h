@@ -108,18 +108,27 @@ constexpr int GST_N = 16;       // q[0..5], p[0..5], psi, sigma_space, sigmoid(u
 // State at the START of day t (gemlib compute_state, call site inference.py:500-510).
 // SRC 0: events fp64 [B][M][T][3] (reference layout); writes Xn, KS.
 // SRC 1: events from the sampler's int32 planes; writes St planes, Xn, rowtot.
+// PART 0: everything.  The fused evaluation (k_state_params / k_eval_tiles) splits the work by what the
+// contraction waits for: PART 1 = the state only (Xn, KS, the per-day I->R partials) -- a short, HBM-bound
+// pass -- and PART 2 = the row constants only (binomial coefficients and the E->I term: the fp64-VALU-heavy
+// part, which nothing but the final sum needs), run beside the matrix-core tiles.  Row block bx of chain by.
 // ---------------------------------------------------------------------------
-template <int SRC>
-__device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const Work &w, const double *__restrict__ events) {
-    extern __shared__ double lds[];                 // [SCAN_WAVES][Tp][2] | lft [SCAN_LFT]
+template <int SRC, int PART = 0>
+__device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const Work &w, const double *__restrict__ events,
+                                          int bx, int by) {
+    extern __shared__ double lds[];                 // PART 0: [SCAN_WAVES][Tp][2] | lft [SCAN_LFT]; 1: no lft; 2: lft only
     __shared__ double2 ltab[LDSTAB_N];
     debug_skew(d);
-    const int b = d.b0 + blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr bool STATE = PART != 2, ROWC = PART != 1;
+    const int b = d.b0 + by, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *mycol = lds + (size_t)wave * d.Tp * 2;
-    double *lft = lds + (size_t)SCAN_WAVES * d.Tp * 2;
-    for (int i = threadIdx.x; i < SCAN_LFT; i += SCAN_WAVES * WAVE) lft[i] = c.lfact_big[i];
-    for (int i = lane; i < d.Tp * 2; i += WAVE) mycol[i] = 0.0;
-    log_table_to_lds(ltab, c.logtab);
+    double *lft = lds + (PART == 2 ? 0 : (size_t)SCAN_WAVES * d.Tp * 2);
+    if (ROWC)
+        for (int i = threadIdx.x; i < SCAN_LFT; i += SCAN_WAVES * WAVE) lft[i] = c.lfact_big[i];
+    if (STATE)
+        for (int i = lane; i < d.Tp * 2; i += WAVE) mycol[i] = 0.0;
+    if (ROWC) log_table_to_lds(ltab, c.logtab);
+    else __syncthreads();
     // log(n!): LDS table below SCAN_LFT (one ds_read instead of ~40 dependent fp64 operations), Stirling above
     auto lf = [&](double n) { return n < (double)SCAN_LFT ? lft[(int)n] : lfact(n, ltab); };
     auto lb = [&](double n, double k) { return (k < 0.0 || k > n) ? -INFINITY : lf(n) - lf(k) - lf(n - k); };
@@ -130,7 +139,7 @@ __device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const 
     constexpr int RPW = SCAN_ROWS / SCAN_WAVES;
     constexpr int CB = SCAN_CB;                      // day chunks loaded per batch, before any arithmetic
     for (int r = 0; r < RPW; ++r) {
-        const int m = blockIdx.x * SCAN_ROWS + wave * RPW + r;
+        const int m = bx * SCAN_ROWS + wave * RPW + r;
         if (m >= d.M) break;
         const double S0 = c.init[m * 4 + 0], E0 = c.init[m * 4 + 1], I0 = c.init[m * 4 + 2];
         const double invN = c.invN[m];
@@ -168,16 +177,22 @@ __device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const 
                              iir = wave_incl_scan(kir[j], lane);
                 const double xse = cse + ise - kse[j], xei = cei + iei - kei[j], xir = cir + iir - kir[j];
                 const double S = S0 - xse, E = E0 + xse - xei, I = I0 + xei - xir;
-                w.Xn[rowoff + t] = valid ? I * invN : 0.0;
-                if (w.Xn32 != nullptr) w.Xn32[rowoff + t] = valid ? (float)(I * invN) : 0.f;
-                if (SRC == 0) {
-                    w.KS[rowoff + t] = valid ? make_int2((int)kse[j], (int)(S - kse[j])) : make_int2(0, 0);
-                } else {
-                    w.St[0][rowoff + t] = valid ? (int)S : 0;
-                    w.St[1][rowoff + t] = valid ? (int)E : 0;
-                    w.St[2][rowoff + t] = valid ? (int)I : 0;
+                if (STATE) {
+                    w.Xn[rowoff + t] = valid ? I * invN : 0.0;
+                    if (w.Xn32 != nullptr) w.Xn32[rowoff + t] = valid ? (float)(I * invN) : 0.f;
+                    if (SRC == 0) {
+                        w.KS[rowoff + t] = valid ? make_int2((int)kse[j], (int)(S - kse[j])) : make_int2(0, 0);
+                    } else {
+                        w.St[0][rowoff + t] = valid ? (int)S : 0;
+                        w.St[1][rowoff + t] = valid ? (int)E : 0;
+                        w.St[2][rowoff + t] = valid ? (int)I : 0;
+                    }
+                    if (valid) {
+                        mycol[t * 2 + 0] += kir[j];
+                        mycol[t * 2 + 1] += I - kir[j];
+                    }
                 }
-                if (valid) {
+                if (ROWC && valid) {
                     // S only ever loses its events (S_{t+1} = S_t - k_t), so its binomial coefficients telescope:
                     //   sum_t [lf(S_t) - lf(k_t) - lf(S_t - k_t)] = lf(S_0) - lf(S_T) - sum_t lf(k_t)
                     // -- one small-argument term per cell here, the two large ones once per row below; E and I
@@ -185,27 +200,28 @@ __device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const 
                     rc += (kse[j] < 0.0 || kse[j] > S) ? -INFINITY : -lf(kse[j]);
                     rc += lb(E, kei[j]) + lb(I, kir[j]);
                     rc += kei[j] * L_ei - (E - kei[j]) * r_ei;
-                    mycol[t * 2 + 0] += kir[j];
-                    mycol[t * 2 + 1] += I - kir[j];
                 }
                 cse += __shfl(ise, WAVE - 1, WAVE);
                 cei += __shfl(iei, WAVE - 1, WAVE);
                 cir += __shfl(iir, WAVE - 1, WAVE);
             }
         }
-        rc = wave_sum(rc);
+        if (ROWC) rc = wave_sum(rc);
         if (lane == 0) {
             // the telescoped ends (cse = all S->E events of the row); an exhausted S already produced -inf above
-            rc += S0 - cse >= 0.0 ? lfact(S0, ltab) - lfact(S0 - cse, ltab) : -INFINITY;
-            w.rowconst[(size_t)b * d.Mp + m] = rc;
+            if (ROWC) {
+                rc += S0 - cse >= 0.0 ? lfact(S0, ltab) - lfact(S0 - cse, ltab) : -INFINITY;
+                w.rowconst[(size_t)b * d.Mp + m] = rc;
+            }
             if (SRC == 1) {
                 w.rowtot[((size_t)b * 2 + 0) * d.Mp + m] = (int)cse;
                 w.rowtot[((size_t)b * 2 + 1) * d.Mp + m] = (int)cei;
             }
         }
     }
+    if (!STATE) return;
     __syncthreads();
-    double *out = w.colIR + ((size_t)b * d.nrb_scan + blockIdx.x) * d.Tp * 2;
+    double *out = w.colIR + ((size_t)b * d.nrb_scan + bx) * d.Tp * 2;
     const int n = d.Tp * 2;
     for (int i = threadIdx.x; i < n; i += SCAN_WAVES * WAVE) {
         double a = 0.0;
@@ -217,12 +233,12 @@ __device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const 
 
 template <int SRC>
 __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
-    scan_rows<SRC>(d, c, w, events);
+    scan_rows<SRC>(d, c, w, events, blockIdx.x, blockIdx.y);
 }
 
 // Grid (Tp/64, chains): Kir_t, Dir_t of 64 days per workgroup (integer-valued, exact in any
 // order); block 0 of a chain also sums the row constants.
-__device__ __forceinline__ void colreduce_block(const Dims &d, const Work &w, int bx, int by) {
+__device__ __forceinline__ void colreduce_block(const Dims &d, const Work &w, int bx, int by, bool with_const = true) {
     __shared__ double sh[4];
     __shared__ double2 part[4][WAVE];
     debug_skew(d);
@@ -248,7 +264,7 @@ __device__ __forceinline__ void colreduce_block(const Dims &d, const Work &w, in
         w.Kir[(size_t)b * d.Tp + t] = (p0.x + p1.x) + (p2.x + p3.x);
         w.Dir[(size_t)b * d.Tp + t] = (p0.y + p1.y) + (p2.y + p3.y);
     }
-    if (bx == 0) {
+    if (bx == 0 && with_const) {
         double acc = 0.0;
         for (int m = threadIdx.x; m < d.M; m += 256) acc += w.rowconst[(size_t)b * d.Mp + m];
         acc = block_sum_256(acc, sh);
@@ -782,7 +798,329 @@ __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan_params(Dims d, Const
         param_tables(d, c, w, d.b0 + blockIdx.y, u_all + (size_t)(d.b0 + blockIdx.y) * d.P, seg, sh);
         return;
     }
-    scan_rows<0>(d, c, w, events);
+    scan_rows<0>(d, c, w, events, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------
+// The fused stateless evaluation (seir_log_prob_dev): three launches instead of four, and nothing on the
+// critical path that the contraction does not need.
+//   k_state_params  [state scan, PART 1 | parameter tables]          HBM-bound: events in, Xn / KS out
+//   k_eval_tiles    [contraction tiles with the S->E term as their epilogue | row constants (scan PART 2) |
+//                    fold of the scan's I->R partials]
+//   k_finish        reduction (sums the row constants itself: with_rowconst)
+// The contraction is bound by the matrix cores and leaves the vector ALUs idle; the row constants are bound by
+// the vector ALUs and use no matrix core: both kinds of workgroup have 8 waves and at most 128 VGPRs, so one of
+// each fits a CU (2 + 2 waves per SIMD) and the hardware interleaves them.  The S->E term is evaluated on the
+// accumulators of the tile (D layout of v_mfma_f64_16x16x4_f64: lane l holds rows (l>>4)+4r, column l&15), so F
+// makes no round trip through memory before it is used (it is still written once: seir_eval_prepared_dev reads it).
+// The epilogue's operands (KS, Xn) are fetched behind the MFMAs of the last K chunk.
+// Tile 64 rows x TN days (TN = 96 or 64), 8 waves = 4 row blocks of 16 x 2 column groups of TN/2.
+// Partial sums: Lpart / Ppart per tile, Kpart [Mp/64][Tp], Rpart [Tp/TN][Mp] -- the Dims handed to this kernel
+// and to k_finish carry nmt = Mp/64, ntc = Tp/TN.
+// ---------------------------------------------------------------------------
+// K chunk of the fused tile.  The panels are double-buffered in LDS and two chunks are in flight in registers, so a
+// chunk's global loads are issued two chunks (~1.3 us of matrix work) before they are needed and there is one
+// barrier per chunk; 16 keeps the dynamic LDS (which every workgroup of the launch is given, the row-constant
+// ones too) at the ~54 KB of the epilogue's tile, so that two workgroups fit a CU.
+constexpr int GSE_KC = 16;
+template <int TN>
+__host__ __device__ inline size_t gemm_se_lds_bytes() {
+    const size_t panels = (size_t)2 * GSE_KC * (GEMM_RS + gemm_rsb<TN>()) * sizeof(double);
+    const size_t epi = ((size_t)GEMM_TM * (TN + 2) + 4 * TN + 2 * GEMM_TM + 16) * sizeof(double);
+    return panels > epi ? panels : epi;
+}
+template <bool GRAD, int TN>
+__device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, const Work &w, int bx, int by, int bz) {
+    extern __shared__ double lds[];                 // 2 x (A [KC][RS] | B [KC][RSB]); the epilogue's tile and reduction buffers afterwards
+    __shared__ double2 ltab[LDSTAB_N];
+    __shared__ double vec_t[2 * TN], vec_m[2 * GEMM_TM];      // ea, W of the tile's days; eb, N of its rows
+    constexpr int NT = 512, NCG = 2, RSB = gemm_rsb<TN>(), CW = TN / NCG, NJ = CW / 16;
+    constexpr int PANEL = GSE_KC * (GEMM_RS + RSB);           // doubles per buffer
+    debug_skew(d);
+    const int b = d.b0 + bz, m0 = by * GEMM_TM, t0 = bx * TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave / NCG, wc = wave % NCG;        // row block (16 rows), column group (CW columns)
+    const double *Xb = w.Xn + (size_t)b * d.Mp * d.Tp;
+    constexpr int EA = GSE_KC * (GEMM_TM / 2), EB = GSE_KC * (TN / 2);
+    constexpr int NA = (EA + NT - 1) / NT, NB = (EB + NT - 1) / NT;
+    static_assert(NA == 1 && NB <= 2, "staging is written out for one A and up to two B elements per thread");
+    // Two chunks in flight, in named registers (as arrays behind a reference they ended up in scratch memory).  Every
+    // chunk asked for lies inside the Mp allocated (zero-padded) rows: no bounds checks, no branches around the loads;
+    // the partial second round of the B chunk reads a valid (clamped) element that store_chunk drops.
+    using v2d = __attribute__((ext_vector_type(2))) double;     // native vector: HIP's double2 struct copies became memcpys through scratch
+    struct Stage { v2d a, b0, b1; } s0, s1;
+    const int ea_row = tid / (GEMM_TM / 2), ea_col = (tid % (GEMM_TM / 2)) * 2;
+    const int eb0_row = tid / (TN / 2), eb0_col = (tid % (TN / 2)) * 2;
+    const int e1 = min(tid + NT, EB - 1), eb1_row = e1 / (TN / 2), eb1_col = (e1 % (TN / 2)) * 2;
+    const bool has_b1 = NB > 1 && tid + NT < EB;
+    const double *pa = c.Cstar + (size_t)ea_row * d.Kp0 + m0 + ea_col;
+    const double *pb0 = Xb + (size_t)eb0_row * d.Tp + t0 + eb0_col, *pb1 = Xb + (size_t)eb1_row * d.Tp + t0 + eb1_col;
+#define GSE_LOAD(st, kb)                                                        \
+    do {                                                                        \
+        st.a = *(const v2d *)(pa + (size_t)(kb) * d.Kp0);                   \
+        st.b0 = *(const v2d *)(pb0 + (size_t)(kb) * d.Tp);                  \
+        if (NB > 1) st.b1 = *(const v2d *)(pb1 + (size_t)(kb) * d.Tp);      \
+    } while (0)
+#define GSE_STORE(st, buf)                                                      \
+    do {                                                                        \
+        double *A_ = lds + (buf) * PANEL, *B_ = A_ + GSE_KC * GEMM_RS;          \
+        *(v2d *)(A_ + ea_row * GEMM_RS + ea_col) = st.a;                    \
+        *(v2d *)(B_ + eb0_row * RSB + eb0_col) = st.b0;                     \
+        if (has_b1) *(v2d *)(B_ + eb1_row * RSB + eb1_col) = st.b1;         \
+    } while (0)
+    d4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int ar = lane & 15, ak = lane >> 4;
+    auto mfma_chunk = [&](int buf) {
+        const double *A = lds + buf * PANEL, *Bm = A + GSE_KC * GEMM_RS;
+#pragma unroll
+        for (int kk = 0; kk < GSE_KC; kk += 4) {
+            const double a0 = A[(kk + ak) * GEMM_RS + wr * 16 + ar];
+            const double *bp = Bm + (kk + ak) * RSB + wc * CW + ar;
+            double bf[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = bp[16 * j];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[j], acc[j], 0, 0, 0);
+        }
+    };
+    if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
+    // the tile's slices of the parameter tables: read from LDS by the epilogue instead of living in registers
+    // through the matrix loop
+    if (tid >= 256 && tid < 256 + TN) {
+        vec_t[tid - 256] = w.ea[(size_t)b * d.Tp + t0 + tid - 256];
+        vec_t[TN + tid - 256] = c.W[t0 + tid - 256];
+    }
+    if (tid >= 384 && tid < 384 + GEMM_TM) {
+        vec_m[tid - 384] = w.eb[(size_t)b * d.Mp + m0 + tid - 384];
+        vec_m[GEMM_TM + tid - 384] = c.N[m0 + tid - 384];
+    }
+    // K runs to Kp rounded up to a PAIR of chunks: Cstar and Xn are allocated and zero up to Mp = ceil64(M) rows,
+    // so the extra rows add exact zeros
+    const int nch = 2 * ((d.Kp + 2 * GSE_KC - 1) / (2 * GSE_KC));
+    // (lds_barrier, not __syncthreads: the latter also waits for the global loads just issued)
+    GSE_LOAD(s0, 0);
+    GSE_LOAD(s1, GSE_KC);
+    GSE_STORE(s0, 0);
+    if (nch > 2) GSE_LOAD(s0, 2 * GSE_KC);
+    lds_barrier();
+    int k = 0;
+    for (; k + 2 < nch; k += 2) {
+        // chunk k from buffer 0; chunk k + 1 goes to buffer 1 (free since the barrier that ended chunk k - 1)
+        mfma_chunk(0);
+        GSE_STORE(s1, 1);
+        if (k + 3 < nch) GSE_LOAD(s1, (k + 3) * GSE_KC);
+        lds_barrier();
+        // chunk k + 1 from buffer 1; chunk k + 2 goes to buffer 0
+        mfma_chunk(1);
+        GSE_STORE(s0, 0);
+        if (k + 4 < nch) GSE_LOAD(s0, (k + 4) * GSE_KC);
+        lds_barrier();
+    }
+    // the last pair of chunks, with the epilogue's first operands in flight behind it.  Cell (r, j) of this lane:
+    // row m0 + wr*16 + ak + 4r, day t0 + wc*CW + j*16 + ar; the operands of column block 0 are fetched here,
+    // block j + 1's while block j is evaluated
+    mfma_chunk(0);
+    GSE_STORE(s1, 1);
+    lds_barrier();
+    using v2i = __attribute__((ext_vector_type(2))) int;
+    v2i ks[4];
+    double xn[4];
+    const int lr0 = wr * 16 + ak, lc0 = wc * CW + ar;          // local row / column of cell (0, 0)
+    const size_t q00 = ((size_t)b * d.Mp + m0 + lr0) * d.Tp + t0 + lc0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ks[r] = *(const v2i *)(w.KS + q00 + (size_t)(4 * r) * d.Tp);
+        xn[r] = w.Xn[q00 + (size_t)(4 * r) * d.Tp];
+    }
+    const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
+    mfma_chunk(1);
+    lds_barrier();                                   // the panels are dead: their LDS carries the tile and the reductions
+    // The accumulators go to LDS and the cells are evaluated by a rolled loop over the column blocks: unrolled, the
+    // twelve cells of a lane (each with its series / libm branch) need far more than the 128 registers that let a
+    // row-constant workgroup share the CU.
+    constexpr int FS = TN + 2;
+    double *Ft = lds;                                // [64][FS]
+    double *ep_col = lds + GEMM_TM * FS;             // [4 row blocks][TN]
+    double *ep_sc = ep_col + 4 * TN;                 // [8 waves][2]
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ft[(lr0 + 4 * r) * FS + lc0 + 16 * j] = acc[j][r];
+    // each lane reads back exactly what it wrote: no barrier
+    double ll = 0.0, gpsi = 0.0;
+    int nbad = 0;
+#ifdef EVAL_X_NO_EPI
+    if (d.M > 0) return;
+#endif
+    // Hot pass: every cell through the small-rate series, no branch in the cell code (cells interleave freely and the
+    // libm branch's registers are not live here); a cell whose rate is outside the series' range contributes nothing
+    // and is counted.  The d/d eta of a cell replaces its F in the LDS tile (F has been written out by then).
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+        v2i ksn[4];
+        double xnn[4];
+        const bool more = j + 1 < NJ;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t q = q00 + (size_t)(4 * r) * d.Tp + 16 * (more ? j + 1 : j);
+            ksn[r] = *(const v2i *)(w.KS + q);
+            xnn[r] = w.Xn[q];
+        }
+        const double ea_t = vec_t[lc0 + 16 * j], Wt = vec_t[TN + lc0 + 16 * j];
+        const double psiW = psi * Wt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int li = (lr0 + 4 * r) * FS + lc0 + 16 * j;
+            const double F = Ft[li];
+            w.F[q00 + (size_t)(4 * r) * d.Tp + 16 * j] = F;
+            const double I = rint(xn[r] * vec_m[GEMM_TM + lr0 + 4 * r]), kse = (double)ks[r].x, snk = (double)ks[r].y;
+            const double ee = ea_t * vec_m[lr0 + 4 * r];
+            const double lam0 = ee * (I + psiW * F);
+            const double rr = (lam0 + d.rate_floor) * d.dt;
+            const bool ok = rr >= L1ME_SERIES_MIN && rr <= L1ME_SERIES_MAX;      // false for NaN
+            double L, inv;
+            l1me_inv_series(ok ? rr : L1ME_SERIES_MAX, L, inv, ltab);
+            const bool has = kse != 0.0;
+            const double cll = (has ? kse * L : 0.0) - snk * rr;
+            ll += ok ? cll : 0.0;
+            if (GRAD) {
+                const double gl = d.dt * ((has ? kse * inv : 0.0) - snk);
+                Ft[li] = ok ? gl * lam0 : 0.0;
+                gpsi += ok ? gl * ee * Wt * F : 0.0;
+            }
+            nbad += ok ? 0 : 1;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ks[r] = ksn[r]; xn[r] = xnn[r]; }
+    }
+    // Cold pass, only in a wave that counted such a cell (large hazards, or the NaN of a negative rate): the cells
+    // again, one at a time, those outside the range through l1me_inv's libm branch.
+    if (__builtin_amdgcn_ballot_w64(nbad != 0) != 0) {
+#pragma unroll 1
+        for (int cell = 0; cell < 4 * NJ; ++cell) {
+            const int j = cell >> 2, r = cell & 3;
+            const size_t q = q00 + (size_t)(4 * r) * d.Tp + 16 * j;
+            const double F = w.F[q];                              // this thread's own store above
+            const v2i k2 = *(const v2i *)(w.KS + q);
+            const double Wt = vec_t[TN + lc0 + 16 * j];
+            const double I = rint(w.Xn[q] * vec_m[GEMM_TM + lr0 + 4 * r]), kse = (double)k2.x, snk = (double)k2.y;
+            const double ee = vec_t[lc0 + 16 * j] * vec_m[lr0 + 4 * r];
+            const double lam0 = ee * (I + psi * Wt * F);
+            const double rr = (lam0 + d.rate_floor) * d.dt;
+            if (!(rr >= L1ME_SERIES_MIN && rr <= L1ME_SERIES_MAX)) {
+                double L, inv;
+                l1me_inv(rr, L, inv, ltab);
+                const bool has = kse != 0.0;
+                ll += (has ? kse * L : 0.0) - snk * rr;
+                if (GRAD) {
+                    const double gl = d.dt * ((has ? kse * inv : 0.0) - snk);
+                    Ft[(lr0 + 4 * r) * FS + lc0 + 16 * j] = gl * lam0;
+                    gpsi += gl * ee * Wt * F;
+                }
+            }
+        }
+    }
+    ll = wave_sum(ll);
+    if (GRAD) gpsi = wave_sum(gpsi);
+    if (lane == 0) { ep_sc[wave * 2] = ll; ep_sc[wave * 2 + 1] = gpsi; }
+    __syncthreads();
+    const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
+    if (tid == 0) {
+        double a = 0.0, g = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += ep_sc[k * 2]; g += ep_sc[k * 2 + 1]; }
+        w.Lpart[tile] = a;
+        if (GRAD) w.Ppart[tile] = g;
+    }
+    if (GRAD) {
+        // column sums (d/d eta over the tile's 64 rows, per day) and row sums (over its TN days, per row) of the LDS tile
+        {
+            // all 512 threads: 8 lanes per row, each adds TN/8 entries; then the 8 lanes combine by shuffles
+            const int i = tid >> 3, s8 = tid & 7;
+            const double *src = Ft + i * FS + s8;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < TN / 8; ++k) v += src[8 * k];
+            v += __shfl_xor(v, 1, WAVE);
+            v += __shfl_xor(v, 2, WAVE);
+            v += __shfl_xor(v, 4, WAVE);
+            if (s8 == 0) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + m0 + i] = v;
+        }
+        {
+            // 4 row groups of 16 per column: TN x 4 threads (TN = 96: 384, TN = 64: 256), combined through LDS
+            const int t = tid % TN, g4 = tid / TN;
+            if (g4 < 4) {
+                const double *src = Ft + (g4 * 16) * FS + t;
+                double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) { v0 += src[k * FS]; v1 += src[(k + 1) * FS]; }
+                ep_col[g4 * TN + t] = v0 + v1;
+            }
+            __syncthreads();
+            if (tid < TN)
+                w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t0 + tid] =
+                    (ep_col[tid] + ep_col[TN + tid]) + (ep_col[2 * TN + tid] + ep_col[3 * TN + tid]);
+        }
+    }
+}
+
+#undef GSE_LOAD
+#undef GSE_STORE
+
+// One launch for everything between the state and the final reduction: 1-D grid of
+// [contraction + S->E tiles | row-constant blocks | I->R fold blocks]; the tiles have the low ids and are
+// placed first, the vector-ALU work fills in beside them.
+template <bool GRAD, int TN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_eval_tiles(Dims d, Consts c, Work w, const double *__restrict__ events, int nb) {
+    const int per = d.ntc * d.nmt, n_g = per * nb, n_c = d.nrb_scan * nb;
+    int L = blockIdx.x;
+    if (L < n_g) {
+        int bx, by, bz;
+        if (d.aff_nb > 0) {
+            int tile;
+            xcd_affine(L, per, d.aff_nb, bz, tile);
+            bx = tile % d.ntc;
+            by = tile / d.ntc;
+        } else {
+            bx = L % d.ntc;
+            by = (L / d.ntc) % d.nmt;
+            bz = L / per;
+        }
+        gemm_se_tile<GRAD, TN>(d, c, w, bx, by, bz);
+        return;
+    }
+    L -= n_g;
+    if (L < n_c) {
+#ifndef EVAL_X_NO_CONST         // (developer experiments: tools/dev/build_variant.sh)
+        scan_rows<0, 2>(d, c, w, events, L % d.nrb_scan, L / d.nrb_scan);
+#endif
+        return;
+    }
+    L -= n_c;
+    if (threadIdx.x >= 256) return;                         // colreduce_block is written for 256 threads
+    const int ncb = d.Tp / WAVE;
+    colreduce_block(d, w, L % ncb, L / ncb, /*with_const=*/false);
+}
+template <int TN>
+inline size_t eval_tiles_lds_bytes() {
+    const size_t panels = gemm_se_lds_bytes<TN>(), lft = (size_t)SCAN_LFT * sizeof(double);
+    return panels > lft ? panels : lft;
+}
+
+// the state part of the scan and, as one more block per chain, the parameter tables
+__global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_state_params(Dims d, Consts c, Work w, const double *__restrict__ events,
+                                                                    const double *__restrict__ u_all) {
+    if ((int)blockIdx.x == d.nrb_scan) {
+        __shared__ double sh[4];
+        __shared__ double seg[256];
+        if (threadIdx.x >= 256) return;                     // param_tables is written for 256 threads
+        param_tables(d, c, w, d.b0 + blockIdx.y, u_all + (size_t)(d.b0 + blockIdx.y) * d.P, seg, sh);
+        return;
+    }
+    scan_rows<0, 1>(d, c, w, events, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -808,7 +1146,7 @@ __device__ inline double reduce_chain(const Dims &d, const Consts &c, const Work
             const double rate = w.rir[(size_t)b * d.Tp + t];
             const double r = rate * d.dt;
             double L, inv;
-            l1me_inv(r, L, inv, ltab);
+            l1me_inv_wide(r, L, inv, ltab);              // I->R rates are ~0.25-0.5 per day: the 8-term series, not libm
             acc += (kir != 0.0 ? kir * L : 0.0) - dir * r;
             if (GRAD) {
                 const double gr = d.dt * ((kir != 0.0 ? kir * inv : 0.0) - dir);
@@ -861,11 +1199,23 @@ __device__ inline double reduce_chain(const Dims &d, const Consts &c, const Work
     }
     double gpsi = 0.0;
     for (int i = tid; i < ntile; i += 256) gpsi += w.Ppart[(size_t)b * ntile + i];
-    gsig = block_sum_256(gsig, sh);
-    gbeta = block_sum_256(gbeta, sh);
-    gpsi = block_sum_256(gpsi, sh);
-    gg0 = block_sum_256(gg0, sh);
-    gg1 = block_sum_256(gg1, sh);
+    // the five scalar sums in one pass through LDS (seg is free again: the suffix scan is done)
+    {
+        double v5[5] = {gsig, gbeta, gpsi, gg0, gg1};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v5[k] = wave_sum(v5[k]);
+        __syncthreads();
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) seg[(tid >> 6) * 5 + k] = v5[k];
+        }
+        __syncthreads();
+        gsig = (seg[0] + seg[5]) + (seg[10] + seg[15]);
+        gbeta = (seg[1] + seg[6]) + (seg[11] + seg[16]);
+        gpsi = (seg[2] + seg[7]) + (seg[12] + seg[17]);
+        gg0 = (seg[3] + seg[8]) + (seg[13] + seg[18]);
+        gg1 = (seg[4] + seg[9]) + (seg[14] + seg[19]);
+    }
     if (tid == 0) {
         const double s0 = sc[SC_S0], s1 = sc[SC_S1];
         g[0] = (gpsi + 2.0 / psi - 10.0) * s0 + (1.0 - s0);
@@ -879,20 +1229,30 @@ __device__ inline double reduce_chain(const Dims &d, const Consts &c, const Work
 }
 
 // k_finish: joint log-prob (+ gradient) of the API path, one workgroup per chain.
+// with_rowconst (fused evaluation): the row constants were written in the previous launch and are summed here
+// (and left in Work::constsum, as k_colreduce does in the other forms)
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const double *__restrict__ u_all,
-                                               double *__restrict__ logp, double *__restrict__ grad) {
+                                               double *__restrict__ logp, double *__restrict__ grad, int with_rowconst) {
     extern __shared__ double lds_col[];             // [Tp]
     __shared__ double sh[4];
     __shared__ double seg[256];
     __shared__ double2 ltab[LDSTAB_N];
     const int b = d.b0 + blockIdx.x;
+    double rcs = 0.0;
+    if (with_rowconst)
+        for (int m = threadIdx.x; m < d.M; m += 256) rcs += w.rowconst[(size_t)b * d.Mp + m];
     log_table_to_lds(ltab, c.logtab);
     const double lp = reduce_chain<GRAD>(d, c, w, b, u_all + (size_t)b * d.P,
                                          GRAD ? grad + (size_t)b * d.P : nullptr, lds_col, seg, sh, ltab);
+    if (with_rowconst) {
+        __syncthreads();
+        rcs = block_sum_256(rcs, sh);
+        if (threadIdx.x == 0) w.constsum[b] = rcs;
+    }
     if (threadIdx.x == 0) {
         const double *sc = w.scal + (size_t)b * NSCAL;
-        logp[b] = lp + w.constsum[b] + sc[SC_PRIOR] + sc[SC_JAC];
+        logp[b] = lp + (with_rowconst ? rcs : w.constsum[b]) + sc[SC_PRIOR] + sc[SC_JAC];
     }
 }
 

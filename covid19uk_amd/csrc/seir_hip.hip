@@ -54,6 +54,7 @@ struct seir_ctx {
     bool prepared = false;
     int opt_skew = 0, opt_affinity = 3;     // seir_set_option
     int opt_gemm_f32 = 0;
+    int opt_eval_form = 0;            // 0 fused (three launches), 1 four launches
     std::vector<float> cstar32_host;        // fp32 copy of the padded Cstar, uploaded when the option is first set
 };
 
@@ -306,6 +307,10 @@ extern "C" int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value) {
             if (value < 0 || value > 3) return fail(SEIR_ERR_INVALID, "xcd affinity is a 2-bit mask");
             ctx->opt_affinity = value;
             return 0;
+        case SEIR_OPT_EVAL_FORM:
+            if (value < 0 || value > 1) return fail(SEIR_ERR_INVALID, "eval form is 0 (fused) or 1 (four launches)");
+            ctx->opt_eval_form = value;
+            return 0;
         case SEIR_OPT_GEMM_F32: {
             if (value < 0 || value > 1) return fail(SEIR_ERR_INVALID, "gemm_f32 is 0 or 1");
             if (value && !ctx->c.Cstar32) {
@@ -396,9 +401,9 @@ static void launch_se(seir_ctx *ctx, const LaunchCfg &l, bool grad) {
 static void launch_finish(seir_ctx *ctx, const LaunchCfg &l, const double *u, double *logp, double *grad) {
     const size_t lds = (size_t)l.d.Tp * sizeof(double);
     if (grad)
-        hipLaunchKernelGGL(k_finish<true>, dim3(l.nb), dim3(256), lds, l.st, l.d, ctx->c, ctx->w, u, logp, grad);
+        hipLaunchKernelGGL(k_finish<true>, dim3(l.nb), dim3(256), lds, l.st, l.d, ctx->c, ctx->w, u, logp, grad, 0);
     else
-        hipLaunchKernelGGL(k_finish<false>, dim3(l.nb), dim3(256), lds, l.st, l.d, ctx->c, ctx->w, u, logp, grad);
+        hipLaunchKernelGGL(k_finish<false>, dim3(l.nb), dim3(256), lds, l.st, l.d, ctx->c, ctx->w, u, logp, grad, 0);
 }
 
 extern "C" int seir_prepare_events_dev(seir_ctx *ctx, int32_t B, const double *events_dev) {
@@ -428,7 +433,61 @@ extern "C" int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_
     return 0;
 }
 
-// The full evaluation in four launches: [state scan | parameter tables], mobility contraction,
+// The fused form of the full evaluation (default): [state part of the scan | parameter tables],
+// [contraction tiles with the S->E term as epilogue | row constants | fold of the I->R partials], reduction.
+static void launch_state_params(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, const double *events_dev) {
+    const Dims &d = l.d;
+    const size_t lds_a = (size_t)SCAN_WAVES * d.Tp * 2 * sizeof(double);
+    static bool attr_a = false;
+    if (!attr_a && lds_a > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_state_params, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        attr_a = true;
+    }
+    hipLaunchKernelGGL(k_state_params, dim3(d.nrb_scan + 1, l.nb), dim3(SCAN_WAVES * WAVE), lds_a, l.st, d, ctx->c, ctx->w,
+                       events_dev, u_dev);
+}
+// the Dims of the tile launch and of the reduction after it: partial sums per 64 x TN tile
+template <int TN>
+static Dims fused_dims(const LaunchCfg &l) {
+    Dims d = l.d;
+    d.nmt = d.Mp / GEMM_TM;
+    d.ntc = d.Tp / TN;
+    return d;
+}
+template <int TN>
+static void launch_eval_tiles(seir_ctx *ctx, const LaunchCfg &l, const double *events_dev, bool grad) {
+    Dims d = fused_dims<TN>(l);
+    const int B = l.nb;
+    const bool affinity = (l.affinity & 1) && xcd_affinity_applies(d.ntc * d.nmt, B);
+    d.aff_nb = affinity ? B : 0;
+    const size_t lds_b = eval_tiles_lds_bytes<TN>();
+    static bool attr_b = false;
+    if (!attr_b && lds_b > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_eval_tiles<true, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        (void)hipFuncSetAttribute((const void *)k_eval_tiles<false, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        attr_b = true;
+    }
+    const dim3 grid((unsigned)((d.ntc * d.nmt + d.nrb_scan + d.Tp / WAVE) * B));
+    if (grad) hipLaunchKernelGGL((k_eval_tiles<true, TN>), grid, dim3(512), lds_b, l.st, d, ctx->c, ctx->w, events_dev, B);
+    else hipLaunchKernelGGL((k_eval_tiles<false, TN>), grid, dim3(512), lds_b, l.st, d, ctx->c, ctx->w, events_dev, B);
+}
+template <int TN>
+static void launch_finish_fused(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, double *logp_dev, double *grad_dev) {
+    const Dims d = fused_dims<TN>(l);
+    const size_t lds_f = (size_t)d.Tp * sizeof(double);
+    if (grad_dev) hipLaunchKernelGGL(k_finish<true>, dim3(l.nb), dim3(256), lds_f, l.st, d, ctx->c, ctx->w, u_dev, logp_dev, grad_dev, 1);
+    else hipLaunchKernelGGL(k_finish<false>, dim3(l.nb), dim3(256), lds_f, l.st, d, ctx->c, ctx->w, u_dev, logp_dev, grad_dev, 1);
+}
+template <int TN>
+static void launch_eval_fused(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, const double *events_dev,
+                              double *logp_dev, double *grad_dev) {
+    launch_state_params(ctx, l, u_dev, events_dev);
+    launch_eval_tiles<TN>(ctx, l, events_dev, grad_dev != nullptr);
+    launch_finish_fused<TN>(ctx, l, u_dev, logp_dev, grad_dev);
+}
+
+// The full evaluation.  Default: the fused form above.  SEIR_OPT_EVAL_FORM = 1 (and the fp32 contraction option)
+// select the four-launch form: [state scan | parameter tables], mobility contraction,
 // [S->E tiles | fold of the scan's I->R partials], reduction -- the tables depend on u only and the fold
 // feeds the last launch only, so each rides along with the wide kernel next to it.
 extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, const double *events_dev,
@@ -438,18 +497,24 @@ extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, 
     if (!events_dev || !u_dev || !logp_dev) return fail(SEIR_ERR_INVALID, "null u/events/logp pointer");
     const LaunchCfg l = whole(ctx, B);
     Dims d = l.d;
-    const size_t lds = ((size_t)SCAN_WAVES * d.Tp * 2 + SCAN_LFT) * sizeof(double);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_scan_params, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_scan_params, dim3(d.nrb_scan + 1, B), dim3(SCAN_WAVES * WAVE), lds, l.st, d, ctx->c, ctx->w,
-                       events_dev, u_dev);
-    launch_gemm(ctx, l);
-    const bool affinity = (l.affinity & 1) && xcd_affinity_applies(d.ntc * d.nmt, B) && (d.ntc * B) % 8 == 0;
-    d.aff_nb = affinity ? B : 0;
-    const dim3 grid((unsigned)(d.ntc * d.nmt * B + d.ntc * B));
-    if (grad_dev) hipLaunchKernelGGL(k_se_colreduce<true>, grid, dim3(256), 0, l.st, d, ctx->c, ctx->w, B);
-    else hipLaunchKernelGGL(k_se_colreduce<false>, grid, dim3(256), 0, l.st, d, ctx->c, ctx->w, B);
-    launch_finish(ctx, l, u_dev, logp_dev, grad_dev);
+    const bool f32 = ctx->opt_gemm_f32 && ctx->c.Cstar32 && ctx->w.Xn32;
+    if (ctx->opt_eval_form == 0 && !f32) {
+        if (d.Tp % 96 == 0) launch_eval_fused<96>(ctx, l, u_dev, events_dev, logp_dev, grad_dev);
+        else launch_eval_fused<64>(ctx, l, u_dev, events_dev, logp_dev, grad_dev);
+    } else {
+        const size_t lds = ((size_t)SCAN_WAVES * d.Tp * 2 + SCAN_LFT) * sizeof(double);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_scan_params, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_scan_params, dim3(d.nrb_scan + 1, B), dim3(SCAN_WAVES * WAVE), lds, l.st, d, ctx->c, ctx->w,
+                           events_dev, u_dev);
+        launch_gemm(ctx, l);
+        const bool affinity = (l.affinity & 1) && xcd_affinity_applies(d.ntc * d.nmt, B) && (d.ntc * B) % 8 == 0;
+        d.aff_nb = affinity ? B : 0;
+        const dim3 grid((unsigned)(d.ntc * d.nmt * B + d.ntc * B));
+        if (grad_dev) hipLaunchKernelGGL(k_se_colreduce<true>, grid, dim3(256), 0, l.st, d, ctx->c, ctx->w, B);
+        else hipLaunchKernelGGL(k_se_colreduce<false>, grid, dim3(256), 0, l.st, d, ctx->c, ctx->w, B);
+        launch_finish(ctx, l, u_dev, logp_dev, grad_dev);
+    }
     HIP_TRY(hipGetLastError());
     ctx->last_events = events_dev;
     ctx->prepared = true;
@@ -529,7 +594,7 @@ extern "C" int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t
     if (!mean_ms || iters < 1) return fail(SEIR_ERR_INVALID, "bad iters/mean_ms");
     if (!ctx->last_events || !ctx->last_u || !ctx->last_logp)
         return fail(SEIR_ERR_STATE, "run one evaluation before timing a kernel");
-    if (which == SEIR_K_SE_GRAD && !ctx->last_grad)
+    if ((which == SEIR_K_SE_GRAD || which == SEIR_K_TILES_GRAD) && !ctx->last_grad)
         return fail(SEIR_ERR_STATE, "last evaluation had no gradient buffer");
     auto once = [&]() {
         switch (which) {
@@ -537,10 +602,20 @@ extern "C" int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t
             case SEIR_K_GEMM: launch_gemm(ctx, whole(ctx, B)); break;
             case SEIR_K_SE_VALUE: launch_se<0>(ctx, whole(ctx, B), false); break;
             case SEIR_K_SE_GRAD: launch_se<0>(ctx, whole(ctx, B), true); break;
+            case SEIR_K_STATE: launch_state_params(ctx, whole(ctx, B), ctx->last_u, ctx->last_events); break;
+            case SEIR_K_TILES_VALUE:
+            case SEIR_K_TILES_GRAD:
+                if (ctx->d.Tp % 96 == 0) launch_eval_tiles<96>(ctx, whole(ctx, B), ctx->last_events, which == SEIR_K_TILES_GRAD);
+                else launch_eval_tiles<64>(ctx, whole(ctx, B), ctx->last_events, which == SEIR_K_TILES_GRAD);
+                break;
+            case SEIR_K_FINISH_FUSED:
+                if (ctx->d.Tp % 96 == 0) launch_finish_fused<96>(ctx, whole(ctx, B), ctx->last_u, ctx->last_logp, ctx->last_grad);
+                else launch_finish_fused<64>(ctx, whole(ctx, B), ctx->last_u, ctx->last_logp, ctx->last_grad);
+                break;
             default: launch_finish(ctx, whole(ctx, B), ctx->last_u, ctx->last_logp, ctx->last_grad); break;
         }
     };
-    if (which < SEIR_K_SCAN || which > SEIR_K_FINISH) return fail(SEIR_ERR_INVALID, "unknown kernel id %d", which);
+    if (which < SEIR_K_SCAN || which > SEIR_K_FINISH_FUSED) return fail(SEIR_ERR_INVALID, "unknown kernel id %d", which);
     once();                                    // warm
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; ++i) once();

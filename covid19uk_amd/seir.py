@@ -141,10 +141,14 @@ class SeirModel:
     def sync(self):
         _lib.check(self._lib.seir_sync(self._ctx))
 
-    def set_option(self, debug_skew=None, xcd_affinity=None, gemm_f32=None):
-        """Launch options of the context (seir_set_option): the workgroup-timing test hook and the
-        chain <-> XCD block mapping (neither changes a result), and `gemm_f32`: the mobility contraction
+    def set_option(self, debug_skew=None, xcd_affinity=None, gemm_f32=None, eval_form=None):
+        """Launch options of the context (seir_set_option): the workgroup-timing test hook, the
+        chain <-> XCD block mapping and the launch form of `log_prob_dev` ("fused" | "four-launch"; none of
+        them changes a result beyond summation order), and `gemm_f32`: the mobility contraction
         with fp32 operands on the fp32 matrix instruction (BASELINE config 5; ~1e-8 relative on the log-prob)."""
+        if eval_form is not None:
+            form = {"fused": 0, "four-launch": 1}[eval_form]
+            _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_EVAL_FORM, form))
         if gemm_f32 is not None:
             _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_GEMM_F32, int(bool(gemm_f32))))
         if debug_skew is not None:
@@ -161,7 +165,8 @@ class SeirModel:
         _lib.check(self._lib.seir_timer_stop(self._ctx, ctypes.byref(ms_)))
         return float(ms_.value)
 
-    KERNELS = {"scan": 0, "gemm": 1, "se_value": 2, "se_grad": 3, "finish": 4}
+    KERNELS = {"scan": 0, "gemm": 1, "se_value": 2, "se_grad": 3, "finish": 4,
+               "state": 5, "tiles_value": 6, "tiles_grad": 7, "finish_fused": 8}
 
     def time_kernel(self, which: str, B: int, iters: int = 50) -> float:
         """Mean launch duration (ms) of one kernel of the last evaluation."""

@@ -117,8 +117,11 @@ void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context
  *                            config 5).  THIS ONE CHANGES RESULTS: F carries ~1e-7 relative error, the log-prob
  *                            ~1e-8 -- outside the 1e-9 the fp64 path is held to; off by default.  Needs
  *                            ceil64(M) and ceil64(T) to be multiples of 128.
+ *   SEIR_OPT_EVAL_FORM       launch form of seir_log_prob_dev (speed only): 0 (default) = three launches, the S->E term
+ *                            evaluated on the contraction's accumulators and the row constants beside the matrix-core
+ *                            tiles; 1 = the four-launch form (scan, contraction, S->E tiles, reduction)
  * Options are read when a launch is enqueued (for a sampler using graph replay: at capture). */
-enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2 };
+enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2, SEIR_OPT_EVAL_FORM = 3 };
 int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value);
 
 /* Device memory helpers so that a ctypes host can keep inputs resident
@@ -138,7 +141,9 @@ int seir_timer_stop(seir_ctx *ctx, float *ms);
  * context stream with the arguments of the last evaluation and returns the
  * mean launch duration in milliseconds (HIP events). */
 enum { SEIR_K_SCAN = 0, SEIR_K_GEMM = 1, SEIR_K_SE_VALUE = 2, SEIR_K_SE_GRAD = 3,
-       SEIR_K_FINISH = 4 };
+       SEIR_K_FINISH = 4,
+       /* the launches of the fused form (SEIR_OPT_EVAL_FORM 0) */
+       SEIR_K_STATE = 5, SEIR_K_TILES_VALUE = 6, SEIR_K_TILES_GRAD = 7, SEIR_K_FINISH_FUSED = 8 };
 int seir_time_kernel(seir_ctx *ctx, int32_t which, int32_t B, int32_t iters, float *mean_ms);
 
 /* Self-test hook for the device math the kernels share (csrc/device_math.h):

@@ -92,6 +92,28 @@ def test_distinct_events_per_chain(Model):
             assert lp[b] == want or (np.isnan(lp[b]) and np.isnan(want))
 
 
+@pytest.mark.parametrize("form", ["fused", "four-launch"])
+def test_large_hazards_take_the_libm_branch(Model, form):
+    """Rates beyond the small-rate series of log(1 - exp(-r)) (r > 1/8): in the fused form those cells are left out
+    of the branch-free pass and redone by the cold pass of the tile epilogue; some waves have them, some do not."""
+    case = H.build_case("ni11", 21, alpha_t_sd=0.005)
+    k = case["k"]
+    u, ev = _batch(case, 4, 21)
+    u[:, 5] += np.array([5.5, 6.5, 7.5, 0.0])               # alpha_0: hazards x245, x665, x1800, x1
+    with Model(case["cov"], case["init"], max_chains=4) as model:
+        model.set_option(eval_form=form)
+        lp = _check(case, model, u, ev, grad=True)
+        _check(case, model, u, ev, grad=False)
+    assert np.isfinite(lp).all()
+    # the point of the test: the shifted chains have cells beyond the series' range, the last one has none
+    state = so.compute_state(case["init"], ev[0])
+    over = []
+    for b in range(4):
+        lam, _, _ = so.transition_rates(so.unpack(so.constrain(u[b]), k.M, k.T), k, state)
+        over.append(int((lam > 0.125).sum()))
+    assert over[2] > 10 and over[3] == 0, over
+
+
 def test_infeasible_events_are_minus_inf(Model):
     case = H.build_case("micro_2x3", 9)
     ev = case["events"].copy()
@@ -119,11 +141,24 @@ def test_negative_rate_semantics(Model):
         assert np.isnan(model.log_prob(u, ev))
 
 
-def test_uk380_batch_matches_c_oracle(Model):
+@pytest.mark.parametrize("form", ["fused", "four-launch"])
+def test_uk380_batch_matches_c_oracle(Model, form):
     case = H.build_case("uk380", 10, alpha_t_sd=0.005)
     u, ev = _batch(case, 8, 10)
     with Model(case["cov"], case["init"], max_chains=8) as model:
+        model.set_option(eval_form=form)
         _check(case, model, u, ev, grad=True, use_c=True)
+        _check(case, model, u, ev, grad=False, use_c=True)
+
+
+@pytest.mark.parametrize("name,seed,B", [("micro_2x3", 2, 3), ("micro_17x70", 4, 2), ("ni11", 5, 16)])
+def test_four_launch_form_matches_numpy_oracle(Model, name, seed, B):
+    """The default (fused) form is what every other test exercises; the four-launch form stays as the cross-check."""
+    case = H.build_case(name, seed, alpha_t_sd=0.005)
+    u, ev = _batch(case, B, seed)
+    with Model(case["cov"], case["init"], max_chains=B) as model:
+        model.set_option(eval_form="four-launch")
+        _check(case, model, u, ev, grad=True)
 
 
 def test_prepared_path_and_linearity_properties_at_full_size(Model):
@@ -141,12 +176,22 @@ def test_prepared_path_and_linearity_properties_at_full_size(Model):
     g1 = torch.empty(B, u.shape[1], dtype=torch.float64, device=dev)
     g2 = torch.empty_like(g1)
     with Model(case["cov"], case["init"], max_chains=B) as model:
+        model.set_option(eval_form="four-launch")          # the same kernels as prepare + eval: same bits
         model.log_prob_dev(ut, evt, lp1, g1)
         model.sync()
         model.prepare_events_dev(evt)
         model.eval_prepared_dev(ut, lp2, g2)
         model.sync()
         assert torch.equal(lp1, lp2) and torch.equal(g1, g2)
+        model.set_option(eval_form="fused")                # default: other tiles, other summation order
+        model.log_prob_dev(ut, evt, lp1, g1)
+        model.sync()
+        assert torch.allclose(lp1, lp2, rtol=1e-13, atol=0.0)
+        gs = torch.maximum(g2.abs(), 1e-6 * g2.abs().amax(dim=1, keepdim=True))
+        assert float(((g1 - g2).abs() / gs).max()) < 1e-9
+        model.eval_prepared_dev(ut, lp2, g2)               # F and the tables left by the fused form serve the prepared path
+        model.sync()
+        assert torch.allclose(lp1, lp2, rtol=1e-13, atol=0.0)
         perm = torch.tensor([3, 1, 7, 0, 2, 6, 5, 4], device=dev)
         model.log_prob_dev(ut[perm].contiguous(), evt[perm].contiguous(), lp2, g2)
         model.sync()

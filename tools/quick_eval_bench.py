@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--workload", default="uk380")
     ap.add_argument("--chains", type=int, default=8)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--form", default="fused", choices=["fused", "four-launch"])
     args = ap.parse_args()
     import torch
     import __graft_entry__ as entry
@@ -35,6 +36,8 @@ def main():
     g = torch.empty(B, u.shape[1], dtype=torch.float64, device=dev)
     out = {"workload": args.workload, "B": B, "M": cov.M, "T": cov.T}
     with SeirModel(cov, init, max_chains=B) as model:
+        model.set_option(eval_form=args.form)
+        out["form"] = args.form
         for grad in (None, g):
             for _ in range(3):
                 model.log_prob_dev(ut, evt, lp, grad)
@@ -56,7 +59,7 @@ def main():
             out["prepared_eval_%s_ms" % ("grad" if grad is not None else "value")] = ms
         model.log_prob_dev(ut, evt, lp, g)
         model.sync()
-        for name in ("scan", "gemm", "se_value", "se_grad", "finish"):
+        for name in ("scan", "gemm", "se_value", "se_grad", "finish", "state", "tiles_value", "tiles_grad", "finish_fused"):
             out["k_%s_us" % name] = 1e3 * model.time_kernel(name, B, args.iters)
     cells = B * cov.M * cov.T
     out["alg_bytes_per_eval"] = 24 * cells + 8 * cov.M * cov.M

@@ -96,14 +96,14 @@ def main():
             "kernel_name": names["FETCH_SIZE"].replace("void seir::", ""),
             "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals.get("WRITE_SIZE"),
             "fetch_factor": f, "traffic_bytes_per_launch": traffic}
-    # matrix-core counters of the stateless evaluation (k_gemm): one SQ pass
+    # matrix-core counters of the stateless evaluation (k_eval_tiles; k_gemm in the four-launch form): one SQ pass
     p = one(os.path.join(raw, "pmc_mfma", "**", "*counter_collection.csv"))
     if p:
         means = counter_means(p)
         write_means(os.path.join(prof, f"{tag}_pmc_mfma.csv"), means)
         mf = {}
         for (k, c), (m, n) in means.items():
-            if "k_gemm" in k:
+            if "k_gemm" in k or "k_eval_tiles" in k:
                 mf.setdefault(k.replace("void seir::", ""), {})[c] = m
         if mf:
             summary["mfma_counters"] = {
