@@ -825,7 +825,7 @@ __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan_params(Dims d, Const
 constexpr int GSE_KC = 16;
 template <int TN>
 __host__ __device__ inline size_t gemm_se_lds_bytes() {
-    const size_t panels = (size_t)2 * GSE_KC * (GEMM_RS + gemm_rsb<TN>()) * sizeof(double);
+    const size_t panels = ((size_t)2 * GSE_KC * (GEMM_RS + gemm_rsb<TN>()) + 2) * sizeof(double);   // + the dummy slot
     const size_t epi = ((size_t)GEMM_TM * (TN + 2) + 4 * TN + 2 * GEMM_TM + 16) * sizeof(double);
     return panels > epi ? panels : epi;
 }
@@ -864,9 +864,9 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
 #define GSE_STORE(st, buf)                                                      \
     do {                                                                        \
         double *A_ = lds + (buf) * PANEL, *B_ = A_ + GSE_KC * GEMM_RS;          \
-        *(v2d *)(A_ + ea_row * GEMM_RS + ea_col) = st.a;                    \
-        *(v2d *)(B_ + eb0_row * RSB + eb0_col) = st.b0;                     \
-        if (has_b1) *(v2d *)(B_ + eb1_row * RSB + eb1_col) = st.b1;         \
+        *(v2d *)(A_ + ea_row * GEMM_RS + ea_col) = st.a;                        \
+        *(v2d *)(B_ + eb0_row * RSB + eb0_col) = st.b0;                         \
+        if (NB > 1) *(v2d *)(has_b1 ? B_ + eb1_row * RSB + eb1_col : lds + 2 * PANEL) = st.b1;  \
     } while (0)
     d4 acc[NJ];
 #pragma unroll
@@ -903,19 +903,22 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
     GSE_LOAD(s0, 0);
     GSE_LOAD(s1, GSE_KC);
     GSE_STORE(s0, 0);
-    if (nch > 2) GSE_LOAD(s0, 2 * GSE_KC);
+    GSE_LOAD(s0, min(2, nch - 1) * GSE_KC);           // unconditional, like every load of the loop (see there)
     lds_barrier();
     int k = 0;
     for (; k + 2 < nch; k += 2) {
         // chunk k from buffer 0; chunk k + 1 goes to buffer 1 (free since the barrier that ended chunk k - 1)
+        // (straight-line body -- no branch around a load or a store, the threads without a second B element store to
+        // a dummy slot, the last iteration re-reads the last chunk -- so that the compiler's s_waitcnt counts stay exact
+        // and a stage really is two chunks ahead)
         mfma_chunk(0);
         GSE_STORE(s1, 1);
-        if (k + 3 < nch) GSE_LOAD(s1, (k + 3) * GSE_KC);
+        GSE_LOAD(s1, (k + 3) * GSE_KC);              // k + 3 <= nch - 1 inside this loop
         lds_barrier();
         // chunk k + 1 from buffer 1; chunk k + 2 goes to buffer 0
         mfma_chunk(1);
         GSE_STORE(s0, 0);
-        if (k + 4 < nch) GSE_LOAD(s0, (k + 4) * GSE_KC);
+        GSE_LOAD(s0, min(k + 4, nch - 1) * GSE_KC);
         lds_barrier();
     }
     // the last pair of chunks, with the epilogue's first operands in flight behind it.  Cell (r, j) of this lane:
@@ -951,9 +954,6 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
     // each lane reads back exactly what it wrote: no barrier
     double ll = 0.0, gpsi = 0.0;
     int nbad = 0;
-#ifdef EVAL_X_NO_EPI
-    if (d.M > 0) return;
-#endif
     // Hot pass: every cell through the small-rate series, no branch in the cell code (cells interleave freely and the
     // libm branch's registers are not live here); a cell whose rate is outside the series' range contributes nothing
     // and is counted.  The d/d eta of a cell replaces its F in the LDS tile (F has been written out by then).
@@ -1094,9 +1094,7 @@ void k_eval_tiles(Dims d, Consts c, Work w, const double *__restrict__ events, i
     }
     L -= n_g;
     if (L < n_c) {
-#ifndef EVAL_X_NO_CONST         // (developer experiments: tools/dev/build_variant.sh)
         scan_rows<0, 2>(d, c, w, events, L % d.nrb_scan, L / d.nrb_scan);
-#endif
         return;
     }
     L -= n_c;
