@@ -140,11 +140,350 @@ __device__ inline void mv_draw(const SamplerCfg &s, const Chains &ch, int b, Mov
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-level form of the proposal (T <= 64 NCH days): the same draws and the same arithmetic as the block
+// form below, organised so that nothing in it waits at a workgroup barrier.  What the block form does with
+// block scans through LDS (count the rows / days that hold events, find the r-th of them, minimum of a
+// compartment over a window of days) one wave does with ballots, population counts and DPP minima over
+// 64 lanes: a row of T days is NCH registers per lane, the M row totals are read from the LDS copy in
+// 64-row pieces.  Wave j draws sub-move j (its row's three planes are fetched by that wave alone, one
+// round trip); the waves meet once, where the block form's last barrier is.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wv_popc(unsigned long long m) { return __builtin_popcountll(m); }
+// position (0..63) of the k-th set bit of `mask`, k < popcount(mask); every lane of the wave must be here
+__device__ __forceinline__ int wv_kth_bit(unsigned long long mask, int k, int lane) {
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    const bool me = ((mask >> lane) & 1ull) != 0ull && below == k;
+    return (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(me));
+}
+// rows of `tot` [0, M) that hold events, as bit masks of 64 rows each: all the LDS reads are issued together, the
+// rest (count, position of the p-th such row) is scalar work on the masks
+constexpr int WV_MCH = 6;                                    // 64-row pieces held as masks (M <= 384); more rows: loops
+struct HotRows {
+    unsigned long long mask[WV_MCH];
+    int H;
+};
+__device__ __forceinline__ HotRows wv_hot_rows(const int *tot, int M, int lane) {
+    HotRows h;
+    h.H = 0;
+    if (M <= WV_MCH * WAVE) {
+        int v[WV_MCH];
+#pragma unroll
+        for (int c = 0; c < WV_MCH; ++c) { const int m = c * WAVE + lane; v[c] = m < M ? tot[m] : 0; }
+#pragma unroll
+        for (int c = 0; c < WV_MCH; ++c) { h.mask[c] = __builtin_amdgcn_ballot_w64(v[c] > 0); h.H += wv_popc(h.mask[c]); }
+    } else {
+#pragma unroll
+        for (int c = 0; c < WV_MCH; ++c) h.mask[c] = 0ull;
+        for (int m0 = 0; m0 < M; m0 += WAVE) {
+            const int m = m0 + lane;
+            h.H += wv_popc(__builtin_amdgcn_ballot_w64(m < M && tot[m] > 0));
+        }
+    }
+    return h;
+}
+// row index of the p-th row that holds events, p < h.H
+__device__ __forceinline__ int wv_hot_row(const HotRows &h, const int *tot, int M, int p, int lane) {
+    int row = 0;
+    bool found = false;
+    if (M <= WV_MCH * WAVE) {
+#pragma unroll
+        for (int c = 0; c < WV_MCH; ++c) {
+            const int cnt = wv_popc(h.mask[c]);
+            if (!found && p < cnt) { row = c * WAVE + wv_kth_bit(h.mask[c], p, lane); found = true; }
+            if (!found) p -= cnt;
+        }
+    } else {
+        for (int m0 = 0; m0 < M; m0 += WAVE) {             // uniform trip count: the ballots see every lane
+            const int m = m0 + lane;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(m < M && tot[m] > 0);
+            const int cnt = wv_popc(mask);
+            if (!found && p < cnt) { row = m0 + wv_kth_bit(mask, p, lane); found = true; }
+            if (!found) p -= cnt;
+        }
+    }
+    return row;
+}
+// value of the per-lane array v[c] (day c*64 + lane) at day t (uniform)
+template <int NCH>
+__device__ __forceinline__ int wv_at(const int (&v)[NCH], int t) {
+    int r = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if ((t >> 6) == c) r = __builtin_amdgcn_readlane(v[c], t & 63);
+    return r;
+}
+
+template <int NCH>
+__device__ inline void mv_propose_wave(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
+                                       MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab,
+                                       bool rows_only) {
+    Move &mv = sm.mv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, M = d.M, T = d.T;
+#ifdef SEIR_STAMPS
+    double *stamp_hs = L.stamp_hs; const bool stamp_on = L.stamp_on;
+#endif
+    MSTAMP(4);
+    const int tgt = spec.tgt;
+    lds_barrier();                                           // publishes sm.u / the header (mv_draw) and the totals in LDS
+    if (spec.kind == 0) {
+        // ---- UncalibratedEventTimesUpdate: every wave finds the rows (cheap, no exchange), wave j draws sub-move j
+        const int *rt = L.rt;
+        const HotRows hr = wv_hot_rows(rt, M, lane);
+        const int H = hr.H;
+        const int nsel = min(min(s.mmax, MMAX), H);
+        // positions of the nsel distinct hot rows: draw j is an index among the H - j rows not yet chosen.  Written with
+        // compile-time indices only (a run-time index would put these few integers in scratch memory, and every
+        // access of this latency chain would be a memory round trip)
+        int pos[MMAX], chosen[MMAX], rowj[MMAX];
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) { pos[j] = 0; rowj[j] = 0; chosen[j] = 0x7fffffff; }
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) {
+            if (j < nsel) {
+                int p = rng_index(sm.u[2 * j][0], H - j);
+#pragma unroll
+                for (int a = 0; a < MMAX; ++a)
+                    if (a < j && p >= chosen[a]) ++p;            // chosen[0..j-1] ascending
+                pos[j] = p;
+                chosen[j] = p;                                   // insert: bubble down
+#pragma unroll
+                for (int a = MMAX - 1; a >= 1; --a)
+                    if (a <= j && chosen[a - 1] > chosen[a]) { const int tmp = chosen[a]; chosen[a] = chosen[a - 1]; chosen[a - 1] = tmp; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+            if (j < nsel) rowj[j] = wv_hot_row(hr, rt, M, pos[j], lane);
+        if (rows_only) {
+            if (tid == 0) {
+                sm.nsel = nsel;
+#pragma unroll
+                for (int j = 0; j < MMAX; ++j)
+                    if (j < nsel) sm.sel[j] = rowj[j];
+            }
+            lds_barrier();
+            return;
+        }
+        MSTAMP(5);
+        if (wave < nsel) {
+            const int j = wave;
+            int m = 0;
+#pragma unroll
+            for (int jj = 0; jj < MMAX; ++jj)
+                if (jj == j) m = rowj[jj];
+            const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
+            int rk[NCH], rsrc[NCH], rdst[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = c * WAVE + lane;
+                const bool in = t < T;                               // (T <= Tp <= 64 NCH)
+                rk[c] = in ? w.K[tgt][rowoff + t] : 0;
+                rsrc[c] = in ? w.St[tgt][rowoff + t] : 0;
+                rdst[c] = in ? w.St[tgt + 1][rowoff + t] : 0;
+            }
+            MSTAMP(6);
+            // day: the floor(u D)-th day with events
+            int D = 0;
+            unsigned long long hot[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { hot[c] = __builtin_amdgcn_ballot_w64(rk[c] > 0); D += wv_popc(hot[c]); }
+            int r = rng_index(sm.u[2 * j][1], D), t = 0;
+            {
+                bool found = false;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int cnt = wv_popc(hot[c]);
+                    if (!found && r < cnt) { t = c * WAVE + wv_kth_bit(hot[c], r, lane); found = true; }
+                    if (!found) r -= cnt;
+                }
+            }
+            MSTAMP(7);
+            const int v = rng_index(sm.u[2 * j + 1][0], 2 * s.dmax);
+            const int delta = v < s.dmax ? v - s.dmax : v - s.dmax + 1;
+            const int t2 = t + delta;
+            if (t2 < 0 || t2 >= T) {                                 // out of range: the whole update is rejected
+                if (lane == 0) {
+                    sm.pend_valid[j] = 0;
+                    mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = 0;
+                    sm.logq_part[j] = 0.0;
+                }
+            } else {
+                const int lo = min(t, t2), hi = max(t, t2);
+                const bool later = delta > 0;
+                // bounds: min over (lo, hi] of the compartment that loses x, and of the one that gains it
+                int mdec = 0x7fffffff, minc = 0x7fffffff;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int tau = c * WAVE + lane;
+                    if (tau > lo && tau <= hi) {
+                        mdec = min(mdec, later ? rdst[c] : rsrc[c]);
+                        minc = min(minc, later ? rsrc[c] : rdst[c]);
+                    }
+                }
+                mdec = wave_min_int(mdec);
+                minc = wave_min_int(minc);
+                MSTAMP(8);
+                const int kt = wv_at<NCH>(rk, t), kt2 = wv_at<NCH>(rk, t2);
+                if (lane == 0) {
+                    const bool dec_unbounded = !later && tgt == 0;   // S: prev_event_id None -> no bound
+                    const bool inc_unbounded = later && tgt == 0;
+                    const int min_dec = dec_unbounded ? 0x7fffffff : mdec;
+                    const int min_inc = minc;
+                    const int xmax = max(0, min(min(s.nmax, kt), min_dec));
+                    const int x = rng_index(sm.u[2 * j + 1][1], xmax + 1);
+                    const int Dn = D - ((x > 0 && x == kt) ? 1 : 0) + ((x > 0 && kt2 == 0) ? 1 : 0);
+                    const long long binc = inc_unbounded ? 0x7fffffffLL : (long long)min_inc + x;
+                    const int xmax_r = (int)max(0LL, min((long long)min(s.nmax, kt2 + x), binc));
+                    // a null sub-move (x == 0) is its own reverse: no correction (see oracle/mcmc_oracle.py,
+                    // event_time_move, and tests/test_invariance*.py)
+                    sm.logq_part[j] = x > 0 ? (-mv_log((double)Dn, ltab) - mv_log((double)(xmax_r + 1), ltab)) -
+                                                  (-mv_log((double)D, ltab) - mv_log((double)(xmax + 1), ltab))
+                                            : 0.0;
+                    sm.pend_valid[j] = 1;
+                    mv.m[j] = m; mv.a[j] = t; mv.b[j] = t2; mv.dka[j] = -x; mv.dkb[j] = x;
+                    mv.lo[j] = lo; mv.hi[j] = hi;
+                    mv.dsrc[j] = later ? x : -x;
+                    mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = x;
+                }
+            }
+        }
+        if (tid == 0) {
+            sm.nsel = nsel;
+#pragma unroll
+            for (int j = 0; j < MMAX; ++j)
+                if (j < nsel) sm.sel[j] = rowj[j];
+        }
+        lds_barrier();
+        MSTAMP(9);
+        if (tid == 0) {
+            // compact the in-range updates (order preserved) and combine the correction
+            int n = 0;
+            double lq = 0.0;
+            for (int j = 0; j < nsel; ++j) {
+                if (sm.pend_valid[j] == 0) { mv.valid = 0; continue; }
+                lq += sm.logq_part[j];
+                if (n != j) {
+                    mv.m[n] = mv.m[j]; mv.a[n] = mv.a[j]; mv.b[n] = mv.b[j]; mv.dka[n] = mv.dka[j];
+                    mv.dkb[n] = mv.dkb[j]; mv.lo[n] = mv.lo[j]; mv.hi[n] = mv.hi[j]; mv.dsrc[n] = mv.dsrc[j];
+                }
+                mv.LO = min(mv.LO, mv.lo[n]); mv.HI = max(mv.HI, mv.hi[n]);
+                if (tgt == 1 && mv.dsrc[n] != 0) mv.any_dI = 1;
+                ++n;
+            }
+            mv.n = n;
+            mv.logq = lq;
+        }
+    } else {
+        // ---- UncalibratedOccultUpdate: one row, drawn by wave 0
+        const int R = s.tr_hi - s.tr_lo;
+        const int *rg = L.rg;
+        int msel = 0;
+        if (wave == 0 || rows_only) {
+            const HotRows hr = wv_hot_rows(rg, M, lane);
+            const int Hd = hr.H;
+            const double u_br = sm.u[0][0], u_m = sm.u[0][1], u_t = sm.u[1][0], u_x = sm.u[1][1];
+            const bool is_del = (u_br < 0.5) && Hd > 0;
+            msel = is_del ? wv_hot_row(hr, rg, M, rng_index(u_m, Hd), lane) : rng_index(u_m, M);
+            if (!rows_only) {
+                MSTAMP(5);
+                const int m = msel;
+                const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
+                int rk[NCH], rsrc[NCH], rdst[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = c * WAVE + lane;
+                    const bool in = t < T;
+                    rk[c] = in ? w.K[tgt][rowoff + t] : 0;
+                    rsrc[c] = in ? w.St[tgt][rowoff + t] : 0x7fffffff;      // neutral in the minima below
+                    rdst[c] = in ? w.St[tgt + 1][rowoff + t] : 0x7fffffff;
+                }
+                // the closed end of the series (state after the last day) is part of every window (t, T]
+                const int end_src = comp_start(d, w, rowoff, tgt, T), end_dst = comp_start(d, w, rowoff, tgt + 1, T);
+                MSTAMP(6);
+                // hot days of the row inside the range; the day of a delete is the floor(u Dm)-th of them
+                int Dm = 0;
+                unsigned long long hot[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = c * WAVE + lane;
+                    hot[c] = __builtin_amdgcn_ballot_w64(t >= s.tr_lo && t < s.tr_hi && rk[c] > 0);
+                    Dm += wv_popc(hot[c]);
+                }
+                int t = s.tr_lo + rng_index(u_t, R);
+                if (is_del) {
+                    int r = rng_index(u_t, Dm);
+                    bool found = false;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int cnt = wv_popc(hot[c]);
+                        if (!found && r < cnt) { t = c * WAVE + wv_kth_bit(hot[c], r, lane); found = true; }
+                        if (!found) r -= cnt;
+                    }
+                }
+                MSTAMP(7);
+                int m0 = 0x7fffffff, m1 = 0x7fffffff;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int tau = c * WAVE + lane;
+                    if (tau > t && tau < T) { m0 = min(m0, rsrc[c]); m1 = min(m1, rdst[c]); }
+                }
+                m0 = min(wave_min_int(m0), end_src);
+                m1 = min(wave_min_int(m1), end_dst);
+                MSTAMP(8);
+                const int kt = wv_at<NCH>(rk, t);
+                if (lane == 0) {
+                    const int min_src = tgt == 0 ? 0x7fffffff : m0, min_dst = m1;
+                    const int rt_m = rg[m];
+                    const double lM = mv_log((double)M, ltab), lR = mv_log((double)R, ltab), l2 = 0.6931471805599453;
+                    int x;
+                    if (!is_del) {
+                        const int xmax = max(0, min(s.occult_nmax, min_src));
+                        x = rng_index(u_x, xmax + 1);
+                        const double qf = (Hd > 0 ? -l2 : 0.0) - lM - lR - mv_log((double)(xmax + 1), ltab);
+                        const int Hd2 = Hd + ((rt_m == 0 && x > 0) ? 1 : 0);
+                        const int Dm2 = Dm + ((kt == 0 && x > 0) ? 1 : 0);
+                        const long long bd = (long long)min_dst + x;
+                        const int xmax_r = (int)max(0LL, min((long long)min(s.occult_nmax, kt + x), bd));
+                        const double qr = (Hd2 > 0 && kt + x > 0)
+                                              ? -l2 - mv_log((double)Hd2, ltab) - mv_log((double)Dm2, ltab) - mv_log((double)(xmax_r + 1), ltab)
+                                              : -INFINITY;
+                        mv.logq = qr - qf;
+                        mv.dka[0] = x; mv.dsrc[0] = -x;
+                    } else {
+                        const int xmax = max(0, min(min(s.occult_nmax, kt), min_dst));
+                        x = rng_index(u_x, xmax + 1);
+                        const double qf = -l2 - mv_log((double)Hd, ltab) - mv_log((double)Dm, ltab) - mv_log((double)(xmax + 1), ltab);
+                        const int Hd2 = Hd - ((x > 0 && rt_m == x) ? 1 : 0);
+                        const long long bs = tgt == 0 ? 0x7fffffffLL : (long long)min_src + x;
+                        const int xmax_r = (int)max(0LL, min((long long)s.occult_nmax, bs));
+                        const double qr = (Hd2 > 0 ? -l2 : 0.0) - lM - lR - mv_log((double)(xmax_r + 1), ltab);
+                        mv.logq = qr - qf;
+                        mv.dka[0] = -x; mv.dsrc[0] = x;
+                    }
+                    mv.n = 1;
+                    mv.m[0] = m; mv.a[0] = t; mv.b[0] = -1; mv.dkb[0] = 0;
+                    mv.lo[0] = t; mv.hi[0] = T - 1;
+                    mv.LO = t; mv.HI = T - 1;
+                    mv.any_dI = (tgt == 1 && x != 0) ? 1 : 0;
+                    mv.tm[0] = m; mv.tt[0] = t; mv.tdt[0] = is_del ? -1 : 1; mv.tx[0] = x;
+                }
+            }
+        }
+        if (tid == 0) { sm.nsel = 1; sm.sel[0] = msel; }
+    }
+    lds_barrier();
+}
+
 // rows_only: stop after the rows are chosen (sm.nsel, sm.sel[j] = row): what a proposal's rows are
 // depends on the row totals and the uniforms only.
 __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
                                   MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab,
                                   bool rows_only = false) {
+    if (d.Tp <= 6 * WAVE) {                                  // up to 384 days: a row is six registers per lane
+        mv_propose_wave<6>(d, w, s, ch, b, spec, sm, L, ltab, rows_only);
+        return;
+    }
     Move &mv = sm.mv;
     const int tid = threadIdx.x, M = d.M, T = d.T, T1 = T + 1;
 #ifdef SEIR_STAMPS
@@ -438,7 +777,7 @@ __device__ __forceinline__ void range_totals_to_lds(const Dims &d, const Work &w
 // next.kind == -2: finalize only and advance the chain's sweep counter (closing launch of a sweep).
 __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
                                                   int have_prev, int pbuf) {
-    extern __shared__ int dyn_i[];                     // block 0: rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
+    extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // block 0: rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm;
     __shared__ Move pend;
     __shared__ double2 ltab[LOGTAB_N];
@@ -750,6 +1089,7 @@ struct PairNote {
     int ok;                           // 1: nothing in this launch invalidated the pre-drawn proposal outright
     int n, rows[MMAX];                // rows of the E->I-type update accepted in this launch
 };
+static_assert(sizeof(PairNote) == (2 + MMAX) * sizeof(int), "k_move_pair writes the note as 2 + MMAX ints");
 
 // grid (R B) x MVB threads, R = 1..3 roles:
 //   role 0, the authoritative workgroup of the chain: (1) finalize the pending E->I-type proposal,
@@ -776,7 +1116,7 @@ struct PairNote {
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
                                                    MoveSpec next, MoveSpec se_next, int have_prev, int have_pre,
                                                    int pbuf, int nbk, int lidx, int dbg) {
-    extern __shared__ int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
+    extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
     __shared__ PairNote note;
@@ -839,8 +1179,9 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     const bool pre_avail = do_se && have_pre;
     if (pre_avail) {
         move_copy(&sm_se.mv, ch.mvs + (size_t)pbuf * s.B + b, 256);
-        if (tid == 320) note = ch.prev[(size_t)pbuf * s.B + b];
-        if (tid == 321 || tid == 322) pre_down[tid - 321] = ch.DownS[((size_t)pbuf * s.B + b) * 2 + (tid - 321)];
+        if (tid >= 320 && tid < 320 + 2 + MMAX)
+            reinterpret_cast<int *>(&note)[tid - 320] = reinterpret_cast<const int *>(ch.prev + (size_t)pbuf * s.B + b)[tid - 320];
+        if (tid == 328 || tid == 329) pre_down[tid - 328] = ch.DownS[((size_t)pbuf * s.B + b) * 2 + (tid - 328)];
     }
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
     unsigned tr_slot = 0xffffffffu;
@@ -1055,14 +1396,14 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     }
     // ---- (4) the note for the next launch about the proposal role 2 is pre-drawing
     if (do_pre && tid == 0) {
-        PairNote nt;
+        // (field by field: a struct assembled in a local and assigned is copied through scratch memory)
+        int *nt = reinterpret_cast<int *>(ch.prev + (size_t)(pbuf ^ 1) * s.B + b);
         // if the wait never happened nothing was written in this launch, and a late role 2 read the final state
-        nt.ok = (!se_acc && !(waited && late2)) ? 1 : 0;
-        nt.n = 0;
-        for (int j = 0; j < MMAX; ++j) nt.rows[j] = -1;
-        if (pend_acc)
-            for (int j = 0; j < pendp->n; ++j) nt.rows[nt.n++] = pendp->m[j];
-        ch.prev[(size_t)(pbuf ^ 1) * s.B + b] = nt;
+        nt[0] = (!se_acc && !(waited && late2)) ? 1 : 0;                       // PairNote::ok
+        const int nrows = pend_acc ? pendp->n : 0;
+        nt[1] = nrows;                                                          // PairNote::n
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) nt[2 + j] = j < nrows ? pendp->m[j] : -1;   // PairNote::rows
     }
 }
 

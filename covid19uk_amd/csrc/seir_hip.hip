@@ -823,6 +823,7 @@ struct seir_sampler {
     SamplerCfg cfg{};
     Chains ch{};
     int record_events = 1;
+    bool move_lds_attr = false;       // the event-update kernels were allowed more than 64 KB of dynamic LDS
     std::vector<void *> allocs;
     // chains are independent: they are split into groups that run on their own streams
     // so that one group's single-workgroup-per-chain kernels overlap another group's wide ones
@@ -1275,6 +1276,11 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         d.aff_nb = aff ? nb : 0;
         const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
+        if (plds > 64 * 1024 && !s->move_lds_attr) {
+            (void)hipFuncSetAttribute((const void *)k_move_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+            (void)hipFuncSetAttribute((const void *)k_move_pa2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+            s->move_lds_attr = true;
+        }
         int have_prev = 0, pbuf = 0;
         if (s->moves_mode != 1 && c.n_scans > 30) s->moves_mode = 1;   // k_move_pair's launch tokens cover 62 launches per sweep
         if (s->moves_mode != 1) {
