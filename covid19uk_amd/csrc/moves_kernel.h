@@ -477,10 +477,13 @@ __device__ inline void mv_propose_wave(const Dims &d, const Work &w, const Sampl
 
 // rows_only: stop after the rows are chosen (sm.nsel, sm.sel[j] = row): what a proposal's rows are
 // depends on the row totals and the uniforms only.
+// WF (compile time, chosen by the host from Tp <= 384): the wave form above; the kernels are instantiated for one form
+// each, so that an instance carries the code of that form only.
+template <bool WF>
 __device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
                                   MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab,
                                   bool rows_only = false) {
-    if (d.Tp <= 6 * WAVE) {                                  // up to 384 days: a row is six registers per lane
+    if (WF) {                                                // up to 384 days: a row is six registers per lane
         mv_propose_wave<6>(d, w, s, ch, b, spec, sm, L, ltab, rows_only);
         return;
     }
@@ -775,6 +778,7 @@ __device__ __forceinline__ void range_totals_to_lds(const Dims &d, const Work &w
 // grid (nrb_d, B), MVB threads.  The pending descriptor is read from buffer pbuf, the next one
 // written to pbuf^1 (late blocks must not see the new one).
 // next.kind == -2: finalize only and advance the chain's sweep counter (closing launch of a sweep).
+template <bool WF>
 __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
                                                   int have_prev, int pbuf) {
     extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // block 0: rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
 #ifdef SEIR_STAMPS
         L.stamp_hs = stamp_hs; L.stamp_on = stamp_on;
 #endif
-        mv_propose(d, w, s, ch, b, next, sm, L, ltab);
+        mv_propose<WF>(d, w, s, ch, b, next, sm, L, ltab);
         MSTAMP(10);
         if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm.mv;
         MSTAMP(11);
@@ -1113,6 +1117,7 @@ static_assert(sizeof(PairNote) == (2 + MMAX) * sizeof(int), "k_move_pair writes 
 //     is a row of a conflict, which role 0 detects on its own -- and the planes' row/range totals, fetched
 //     at entry: role 0 does not write anything before roles 1 and 2 hold them (one-word handshakes,
 //     Chains::hand / hand2; if a role is not there in time role 0 goes on and discards its output).
+template <bool WF>
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
                                                    MoveSpec next, MoveSpec se_next, int have_prev, int have_pre,
                                                    int pbuf, int nbk, int lidx, int dbg) {
@@ -1234,7 +1239,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         L.stamp_hs = stamp_hs; L.stamp_on = rstamp_on;
 #endif
         mv_rows_to_lds(d, w, s, b, mine, pre_ok, pre_nx, fix, L, rtl);
-        mv_propose(d, w, s, ch, b, mine, sm_nx, L, ltab);
+        mv_propose<WF>(d, w, s, ch, b, mine, sm_nx, L, ltab);
         RSTAMP(10);
         Move *out = (role == 1 ? ch.mv : ch.mvs) + (size_t)(pbuf ^ 1) * s.B + b;
         move_copy(out, &sm_nx.mv, MVB - WAVE);             // by the last wave: nobody's loads queue behind the store
@@ -1329,7 +1334,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
             // the pending update was of the other plane (tgt 1): nothing to correct in plane 0's totals
             mv_rows_to_lds(d, w, s, b, se, pre_ok, pre_se, nullptr, L, rtl);
             PSTAMP(2);
-            mv_propose(d, w, s, ch, b, se, sm_se, L, ltab);
+            mv_propose<WF>(d, w, s, ch, b, se, sm_se, L, ltab);
             PSTAMP(3);
         }
         const Move &mv = sm_se.mv;
@@ -1369,7 +1374,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
             const Move *fix = (pend_acc && pendp->tgt == next.tgt) ? pendp : nullptr;
             mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
             PSTAMP(6);
-            mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab, /*rows_only=*/true);
+            mv_propose<WF>(d, w, s, ch, b, next, sm_nx, L, ltab, /*rows_only=*/true);
         }
         if (tid == 0) {
             int conf = late ? 1 : 0;                         // role 1 was not there in time: do not trust it
@@ -1386,7 +1391,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         }
         lds_barrier();
         if (s_conf) {                                        // rare: draw it again from the final state
-            mv_propose(d, w, s, ch, b, next, sm_nx, L, ltab);
+            mv_propose<WF>(d, w, s, ch, b, next, sm_nx, L, ltab);
             move_copy(ch.mvfix + (size_t)(pbuf ^ 1) * s.B + b, &sm_nx.mv, MVB - WAVE);
             const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
             mv_own_rows_to_down(d, c, w, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred,

@@ -1276,9 +1276,12 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         d.aff_nb = aff ? nb : 0;
         const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
+        const bool wf = d.Tp <= 6 * WAVE;                        // wave form of the proposals (moves_kernel.h)
+        auto pair_fn = wf ? k_move_pair<true> : k_move_pair<false>;
+        auto pa2_fn = wf ? k_move_pa2<true> : k_move_pa2<false>;
         if (plds > 64 * 1024 && !s->move_lds_attr) {
-            (void)hipFuncSetAttribute((const void *)k_move_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-            (void)hipFuncSetAttribute((const void *)k_move_pa2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+            (void)hipFuncSetAttribute((const void *)pair_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+            (void)hipFuncSetAttribute((const void *)pa2_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             s->move_lds_attr = true;
         }
         int have_prev = 0, pbuf = 0;
@@ -1296,7 +1299,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                     const bool pre = s->moves_mode == 0 && pair + 1 < npairs;
                     const int nh = (half + 1) & 1, nscan = scan + (half == 1 ? 1 : 0);
                     const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : MoveSpec{-1, 0, 0, 0};
-                    hipLaunchKernelGGL(k_move_pair, dim3((pre ? 3 : 2) * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch,
+                    hipLaunchKernelGGL(pair_fn, dim3((pre ? 3 : 2) * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch,
                                        se, nx, se_next, have_prev, have_pre, pbuf, nb, pair, s->pair_debug);
                     have_pre = pre ? 1 : 0;
                     pbuf ^= 1;
@@ -1305,7 +1308,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                 }
             if (have_prev) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
-                hipLaunchKernelGGL(k_move_pair, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, none, 1,
+                hipLaunchKernelGGL(pair_fn, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, none, 1,
                                    0, pbuf, nb, 62, 0);
                 // the F band of the last accepted E->I update: by k_record's waves when it runs anyway
                 if (s->record_events) fpend_in_record = 1;
@@ -1316,7 +1319,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             for (int scan = 0; scan < c.n_scans; ++scan)
                 for (int slot = 0; slot < 4; ++slot) {
                     const MoveSpec spec{slot >= 2 ? 1 : 0, slot & 1, slot, scan};
-                    hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
+                    hipLaunchKernelGGL(pa2_fn, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, spec,
                                        have_prev, pbuf);
                     pbuf ^= 1;
                     hipLaunchKernelGGL((k_move_delta<true>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 0);
@@ -1325,7 +1328,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             if (have_prev) {
                 // closing launch: finalize the last proposal and advance the sweep counter
                 const MoveSpec none{-2, 0, 0, 0};
-                hipLaunchKernelGGL(k_move_pa2, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
+                hipLaunchKernelGGL(pa2_fn, gm, dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, 1, pbuf);
                 advanced = 1;
             }
         }
