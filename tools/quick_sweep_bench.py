@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--groups", default="1,2,4,8")
     ap.add_argument("--hmc", default="chunk")
     ap.add_argument("--moves", default="paired")
+    ap.add_argument("--graph", action="store_true", help="replay the sweep as a hipGraph")
     args = ap.parse_args()
     import __graft_entry__ as entry
     entry.build()
@@ -31,7 +32,7 @@ def main():
         if g > B:
             continue
         with SeirModel(cov, init, max_chains=B) as model:
-            with ChainSampler(model, cfg, B, seed=1, trace_capacity=args.sweeps, chain_groups=g, hmc=args.hmc, moves=args.moves) as s:
+            with ChainSampler(model, cfg, B, seed=1, trace_capacity=args.sweeps, chain_groups=g, hmc=args.hmc, moves=args.moves, use_graph=args.graph) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=1.2e-5)
                 s.reset_trace(); s.run(10); model.sync()
