@@ -96,9 +96,10 @@ struct Work {
     double *gst;           // [B][2][GST_N] the six global parameters, their momenta, psi, sigma and the two sigmoids
     double *Vt;            // [B][Tp]  V(t) = sum_{s=1..t} var[alpha_t[s-1]]
     double *acur;          // [B][Tp]  a_t = alpha_0 + cumsum(alpha_t)[t-1] at the current position
-    double *rirc;          // [B][2][Tp] I->R rate table of the chunked steps, double-buffered: every T-chunk reads all of
-                           //            the current one while the others write theirs for the next position
+    double *rirc;          // (unused since the chunked steps hand each other the I->R gradient parts, Work::CG)
     double *CT;            // [B][2][CT_MAXC][4] per 64-day chunk: sum alpha, sum v p, sum v alpha (double-buffered)
+    double *CG;            // [B][2][CT_MAXC][2] per 64-day chunk: its part of d/d gamma0, d/d gamma1 of the I->R term at the
+                           //            position the step arrives at (double-buffered like CT)
 };
 constexpr int CT_MAXC = 16;     // Tp/64 <= 16 (T <= 1024)
 constexpr int GST_N = 16;       // q[0..5], p[0..5], psi, sigma_space, sigmoid(u0), sigmoid(u1)

@@ -607,7 +607,6 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
                 w.ea[(size_t)b * d.Tp + t] = exp(acc);
                 const double rnew = exp(ng0 + ng1 * wdt[k]);
                 w.rir[(size_t)b * d.Tp + t] = rnew;
-                if (STAGE == 0 && d.chunked) w.rirc[((size_t)b * 2 + 0) * d.Tp + t] = rnew;
             }
             if (STAGE == 0 && d.chunked) {
                 // hand-over to the chunked leapfrog steps: a_t, and per 64-day chunk (= one wave here)
@@ -615,10 +614,24 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
                 if (t < T) w.acur[(size_t)b * d.Tp + t] = acc;
                 const double vv = (t >= 1 && t < T) ? va[k] : 0.0;
                 const double ca = wave_sum(v), cvp = wave_sum(vv * pa[k]), cva = wave_sum(vv * v);
+                // ... and the chunk's part of the I->R term's d/d gamma0, d/d gamma1 at the new rates (each chunked step
+                // leaves the same for the next one: a step then adds ntc pairs instead of evaluating every day again)
+                double cg0 = 0.0, cg1 = 0.0;
+                if (t < T) {
+                    const double rnew = exp(ng0 + ng1 * wdt[k]);
+                    double L, inv;
+                    l1me_inv_wide(rnew * d.dt, L, inv, ltab);
+                    const double grr = d.dt * ((kir[k] != 0.0 ? kir[k] * inv : 0.0) - dir[k]);
+                    cg0 = grr * rnew;
+                    cg1 = grr * rnew * wdt[k];
+                }
+                cg0 = wave_sum(cg0); cg1 = wave_sum(cg1);
                 const int chunk = (tid >> 6) + k * (HB / WAVE);
                 if ((tid & 63) == 0 && chunk < d.ntc) {
                     double *ct = w.CT + (((size_t)b * 2 + 0) * CT_MAXC + chunk) * 4;
                     ct[0] = ca; ct[1] = cvp; ct[2] = cva;
+                    double *cg = w.CG + (((size_t)b * 2 + 0) * CT_MAXC + chunk) * 2;
+                    cg[0] = cg0; cg[1] = cg1;
                 }
             }
         }
@@ -791,32 +804,13 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
         const double *ctr = w.CT + (((size_t)b * 2 + par) * CT_MAXC) * 4;
         const double cta_l = lane < ntc ? ctr[lane * 4] : 0.0, ctvp_l = lane < ntc ? ctr[lane * 4 + 1] : 0.0,
                      ctva_l = lane < ntc ? ctr[lane * 4 + 2] : 0.0;
-        // I->R gradient (gamma0, gamma1): every T-chunk sums all days, they are few
-        double kirv[NC], dirv[NC], ratev[NC], wdv[NC];
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const int tt = j * WAVE + lane;
-            const bool on = j < ntc && tt < T;
-            kirv[j] = on ? w.Kir[(size_t)b * d.Tp + tt] : 0.0;
-            dirv[j] = on ? w.Dir[(size_t)b * d.Tp + tt] : 0.0;
-            ratev[j] = on ? w.rirc[((size_t)b * 2 + par) * d.Tp + tt] : 1.0;
-            wdv[j] = on ? c.wd[tt] : 0.0;
-        }
+        // I->R gradient (gamma0, gamma1): the chunks' parts, left by the previous step (Work::CG) -- ntc pairs instead
+        // of one series evaluation per day of the whole series in every chunk
+        const double *cgr = w.CG + (((size_t)b * 2 + par) * CT_MAXC) * 2;
+        const double cg0_l = lane < ntc ? cgr[lane * 2] : 0.0, cg1_l = lane < ntc ? cgr[lane * 2 + 1] : 0.0;
+        const double kir_t = t < T ? w.Kir[(size_t)b * d.Tp + t] : 0.0, dir_t = t < T ? w.Dir[(size_t)b * d.Tp + t] : 0.0;
         lds_barrier();                                     // ltab (single wave: orders the LDS writes)
-        double gg0 = 0.0, gg1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const int tt = j * WAVE + lane;
-            if (j < ntc && tt < T) {
-                double L, inv;
-                l1me_inv_wide(ratev[j] * d.dt, L, inv, ltab);
-                const double grr = d.dt * ((kirv[j] != 0.0 ? kirv[j] * inv : 0.0) - dirv[j]);
-                gg0 += grr * ratev[j];
-                gg1 += grr * ratev[j] * wdv[j];
-            }
-        }
-        gg0 = wave_sum(gg0);
-        gg1 = wave_sum(gg1);
+        const double gg0 = wave_sum(cg0_l), gg1 = wave_sum(cg1_l);
         // Everything that couples the chunks is linear in the tile scalars, so each lane forms its
         // row tile's share and three wave sums finish the job:
         //   later = sum_{c' > ci} B(c'),  allB = sum B,
@@ -845,17 +839,26 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
         const double pg1n = pg1 + eps * (gg1 - g1 / 1.0e4), g1n = g1 + eps * vg1 * pg1n;
         const double a_new = a0n + pre + wave_incl_scan(an, lane);
         if (own) { q[oT + t] = an; p[oT + t] = pn; }
+        double ng0p = 0.0, ng1p = 0.0;
         if (t < T) {
             w.acur[(size_t)b * d.Tp + t] = a_new;
             w.ea[(size_t)b * d.Tp + t] = exp(a_new);
             const double rnew = exp(g0n + g1n * wd_t);
-            w.rir[(size_t)b * d.Tp + t] = rnew;            // read by nobody in this launch (the chunks read rirc[par])
-            w.rirc[((size_t)b * 2 + (par ^ 1)) * d.Tp + t] = rnew;
+            w.rir[(size_t)b * d.Tp + t] = rnew;            // read by nobody in this launch
+            // this chunk's part of the I->R gradient at the new rates, for the next step
+            double L, inv;
+            l1me_inv_wide(rnew * d.dt, L, inv, ltab);
+            const double grr = d.dt * ((kir_t != 0.0 ? kir_t * inv : 0.0) - dir_t);
+            ng0p = grr * rnew;
+            ng1p = grr * rnew * wd_t;
         }
         const double ca = wave_sum(an), cvp = wave_sum(v * pn), cva = wave_sum(v * an);
+        const double ng0s = wave_sum(ng0p), ng1s = wave_sum(ng1p);
         if (lane == 0) {
             double *ctw = w.CT + (((size_t)b * 2 + (par ^ 1)) * CT_MAXC + ci) * 4;
             ctw[0] = ca; ctw[1] = cvp; ctw[2] = cva;
+            double *cgw = w.CG + (((size_t)b * 2 + (par ^ 1)) * CT_MAXC + ci) * 2;
+            cgw[0] = ng0s; cgw[1] = ng1s;
             if (ci == 0) {
                 q[3] = g0n; q[4] = g1n; q[5] = a0n; p[3] = pg0n; p[4] = pg1n; p[5] = pa0n;
                 gw[3] = g0n; gw[4] = g1n; gw[5] = a0n; gw[9] = pg0n; gw[10] = pg1n; gw[11] = pa0n;

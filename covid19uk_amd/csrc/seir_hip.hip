@@ -877,7 +877,7 @@ extern "C" void seir_sampler_destroy(seir_sampler *s) {
     Work &w = s->ctx->w;
     for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
     w.rowtot = w.rngtot = nullptr;
-    w.TS = w.sp = w.gst = w.Vt = w.acur = w.rirc = w.CT = nullptr;
+    w.TS = w.sp = w.gst = w.Vt = w.acur = w.rirc = w.CT = w.CG = nullptr;
     delete s;
 }
 
@@ -949,6 +949,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(w.acur, (size_t)ctx->Bmax * d.Tp);
     S_ALLOC(w.rirc, (size_t)ctx->Bmax * 2 * d.Tp);
     S_ALLOC(w.CT, (size_t)ctx->Bmax * 2 * CT_MAXC * 4);
+    S_ALLOC(w.CG, (size_t)ctx->Bmax * 2 * CT_MAXC * 2);
     S_ALLOC(ch.q, (size_t)B * d.Pp); S_ALLOC(ch.p, (size_t)B * d.Pp); S_ALLOC(ch.q0, (size_t)B * d.Pp);
     S_ALLOC(ch.grad, (size_t)B * d.Pp); S_ALLOC(ch.var, (size_t)B * d.Pp);
     S_ALLOC(ch.rv_mean, (size_t)B * d.Pp); S_ALLOC(ch.rv_m2, (size_t)B * d.Pp);
