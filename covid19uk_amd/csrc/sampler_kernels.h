@@ -339,7 +339,7 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; zm[k] = m < M ? momentum_normal(key, oM + m) : 0.0; }
         if (tid >= HB - 8 && tid < HB - 2) zz[tid - (HB - 8)] = momentum_normal(key, tid - (HB - 8));
     }
-    if (gather_qs) {                                   // uniform branch
+    if (gather_qs & 1) {                               // uniform branch
 #pragma unroll
         for (int k = 0; k < HM; ++k) { const int m = tid + k * HB; if (m < M) lds_sp[m] = qm[k]; }
         lds_barrier();
@@ -362,7 +362,17 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     STAMP(1);
 
     // ---------------- phase 1: gradient at the current position ---------------
-    double rv[6] = {lpart, 0.0, 0.0, 0.0, 0.0, ppart};  // lik, gg0, gg1, gsig, gbeta, gpsi
+    // prior_here (stage 2 after a chunked last inner step, gather_qs bit 1): nobody left the priors and the Jacobian of
+    // the end point in the scalar block, so they are computed here -- two more sums in the same reduction
+    constexpr int NRV = STAGE == 2 ? 8 : 6;
+    const bool prior_here = STAGE == 2 && (gather_qs & 2) != 0;
+    double rv[NRV] = {lpart, 0.0, 0.0, 0.0, 0.0, ppart};  // lik, gg0, gg1, gsig, gbeta, gpsi [, sum alpha_t^2, s' Q s]
+    if (STAGE == 2 && prior_here) {
+#pragma unroll
+        for (int k = 0; k < HT; ++k) rv[NRV - 2] += qa[k] * qa[k];
+#pragma unroll
+        for (int k = 0; k < HM; ++k) rv[NRV - 1] += qm[k] * qs[k];
+    }
 #pragma unroll
     for (int k = 0; k < HT; ++k) {
         const int t = tid + k * HB;
@@ -382,9 +392,23 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
         rv[4] += lam[k] * Rm[k];
     }
     STAMP(2);
-    block_sum_vec<6>(rv, red);
+    block_sum_vec<NRV>(rv, red);
     STAMP(3);
-    const double lp_theta = rv[0] + prior + jac;
+    double prior_v = prior, jac_v = jac;
+    if (STAGE == 2 && prior_here) {
+        // model_spec.py:140-198 and the bijector's Jacobian (inference.py:555-557), as phase 3 writes them
+        const double e0 = 2.220446049250313e-16;
+        double lp = d.prior_const;
+        lp += -0.5 * a0 * a0 / 100.0 - 0.5 * beta * beta;
+        lp += 2.0 * cold_log(psi) - 10.0 * psi;
+        lp += -0.5 * rv[NRV - 2] / (0.005 * 0.005);
+        lp += -sig * sig / 0.02;
+        lp += -0.5 * rv[NRV - 1];
+        lp += -0.5 * (g0 * g0 + g1 * g1) / 1.0e4;
+        prior_v = lp;
+        jac_v = (q[0] - (psi - e0)) + (q[1] - (sig - e0));      // log sigmoid(u) = u - softplus(u), softplus(u) = value - eps
+    }
+    const double lp_theta = rv[0] + prior_v + jac_v;
     // d/d alpha_t[t-1] = sum_{t' >= t} col[t']: suffix scan, chunks from the back
     double ga[HT], gtot = 0.0;
     {

@@ -1241,12 +1241,12 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             launch_hmc(ctx, l, c, s->ch, 1);
         }
     } else {
-        // inner steps 1..L-2 by independent 64-lane chunks (k_hmc_chunk), the last inner step by the
-        // single-workgroup kernel, which leaves (Q s), priors and Jacobian of the end point for stage 2
+        // all inner steps 1..L-1 by independent 64-lane chunks (k_hmc_chunk); stage 2 then gathers (Q s) and
+        // computes the priors and the Jacobian of the end point itself (gather_qs = 3)
         const int per = d0.ntc + d0.Mp / WAVE;
         const bool aff = (l.affinity & 1) && xcd_affinity_applies(per, nb);
         int par = 0;
-        for (int i = 1; i < c.L - 1; ++i) {
+        for (int i = 1; i < c.L; ++i) {
             l.d.sp_par = par;
             launch_se<1>(ctx, l, true);
             Dims dc = l.d;
@@ -1261,13 +1261,10 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             par ^= 1;
         }
         l.d.sp_par = par;
-        l.d.chunked = 0;
-        launch_se<1>(ctx, l, true);
-        launch_hmc(ctx, l, c, s->ch, 1, /*gather_qs=*/1);
     }
     l.d.chunked = 0;
     launch_se<1>(ctx, l, true);
-    launch_hmc(ctx, l, c, s->ch, 2);
+    launch_hmc(ctx, l, c, s->ch, 2, /*gather_qs=*/chunked ? 3 : 0);
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
     // per update [finalize previous | propose] then the log-ratio over the touched cells
     Dims d = l.d;
