@@ -158,7 +158,10 @@ constexpr int HWV = HB / WAVE;      // waves
 // HT / HM (template parameters): days / rows per thread, ceil(Tp/HB) in {1,2}, ceil(M/HB) in {1,2,4}
 constexpr int NRED = 8;
 #ifdef SEIR_STAMPS
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) ((unsigned long long *)(hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef SEIR_STAMP_STAGE
+#define SEIR_STAMP_STAGE 2
+#endif
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && STAGE == SEIR_STAMP_STAGE) ((unsigned long long *)(hs + 16))[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP_DRAIN(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); STAMP(i); } while (0)
 #else
 #define STAMP(i) do {} while (0)
