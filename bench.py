@@ -168,10 +168,13 @@ def main():
     # --steps the timed region is only ~0.1 s and would otherwise sit on the clock ramp
     spin_sweeps, t_spin = 0, time.perf_counter()
     while time.perf_counter() - t_spin < a.spinup_seconds:
+        # bursts of 100 sweeps whatever K is (sweeps beyond the trace capacity are simply not recorded): with K-sweep
+        # bursts a short --steps run would spin up in 10 ms pieces with a host round trip between them, and the
+        # timed region measured 7 % slower than the steady state
         sampler.reset_trace()
-        sampler.run(min(max(K, 1), 100))
+        sampler.run(100)
         model.sync()
-        spin_sweeps += min(max(K, 1), 100)
+        spin_sweeps += 100
     sampler.reset_trace()
     if world > 1:
         dist.barrier()
@@ -190,6 +193,21 @@ def main():
     t1 = time.perf_counter()
     tr = sampler.read_trace(min(K, sampler.cap))
     d2h = time.perf_counter() - t1
+    # context for `value` when --steps is small: the same sweeps as one uninterrupted run of 400.  Per-sweep time
+    # falls with the length of the uninterrupted run (after a device synchronisation: 0.62 ms for one sweep, 0.59 at 8,
+    # 0.57 at 16-32, 0.55 at 64, 0.54 from ~200 on -- tools/dev/burst_shape.py): the clock climbs over tens of
+    # milliseconds of queued work and any idle gap, however short, restarts the climb.  Not part of `value`.
+    steady = None
+    if K < 200:
+        sampler.reset_trace()
+        torch.cuda.synchronize()
+        model.sync()
+        model.timer_start()
+        sampler.run(400)
+        ms400 = model.timer_stop()
+        steady = {"sweeps": 400, "ms_per_step": ms400 / 400, "samples_per_sec": world * B * 400 / (ms400 * 1e-3),
+                  "note": "one uninterrupted run of 400 sweeps after the timed region (this rank's HIP events); "
+                          "`value` is the --steps sweeps the contract asks for"}
     acc = {"hmc": float(tr.hmc["is_accepted"].mean())}
     for key, mv in tr.moves.items():
         acc[key] = float(mv["is_accepted"].mean())
@@ -361,6 +379,7 @@ def main():
                          "launches_per_sweep": 17},
             "roofline_stateless": stateless,
             "spinup_sweeps": spin_sweeps,
+            "steady_state": steady,
             "log_prob_evals_per_sec": evals,
             "hip_event_ms_per_step": ev_ms / K,
             "pcie_inclusive_samples_per_sec": (world * B * n_bursts * burst / overlapped) if overlapped else None,
