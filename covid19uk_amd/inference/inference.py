@@ -105,6 +105,7 @@ class Posterior:
             self.shapes[f"results/{key}/proposed_delta"] = (4, mmax)
             self.dtypes[f"results/{key}/is_accepted"] = np.int8
         self.num_samples = int(num_samples)
+        self._scratch = {}
         if self.use_h5:
             self._file = hdf5io.File(filename, "w")
             for name, shp in self.shapes.items():
@@ -118,7 +119,17 @@ class Posterior:
 
     def write(self, name, value, first_dim_offset):
         if self.use_h5:
-            self._file.write("/" + name, value, offset=first_dim_offset)
+            v = np.asarray(value)
+            if v.dtype != np.float64 and v.dtype.kind in "iu" and v.nbytes > (1 << 20):
+                # the event tensor arrives as the device's integer counts (a strided view of the burst); it is
+                # converted to the file's float64 in ONE pass into a buffer kept between bursts -- a fresh
+                # 165 MB array per burst costs more in page faults than the conversion itself
+                buf = self._scratch.get(v.shape)
+                if buf is None:
+                    buf = self._scratch[v.shape] = np.empty(v.shape, np.float64)
+                np.copyto(buf, v, casting="unsafe")
+                v = buf
+            self._file.write("/" + name, v, offset=first_dim_offset)
         else:
             v = np.asarray(value)
             self._mem[name][first_dim_offset:first_dim_offset + v.shape[0]] = v
@@ -178,7 +189,7 @@ def draws_to_dict(theta, events, chain):
         "psi": th[:, 0], "sigma_space": th[:, 1], "beta_area": th[:, 2], "gamma0": th[:, 3],
         "gamma1": th[:, 4], "alpha_0": th[:, 5], "alpha_t": th[:, 6:6 + T - 1],
         "spatial_effect": th[:, 6 + T - 1:6 + T - 1 + M],
-        "seir": events[:, chain].astype(DTYPE),
+        "seir": events[:, chain] if events.dtype.kind in "iu" else events[:, chain].astype(DTYPE),   # Posterior.write converts
     }
 
 
