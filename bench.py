@@ -338,7 +338,7 @@ def main():
         sampler.close()
         model.close()
         scaling = {}
-        for Bx in (32, 64):
+        for Bx in (1, 32, 64):                            # 1: BASELINE config 2 (a single chain on one GPU)
             ux = synth.jitter_params(u_true, Bx, scale=0.002, seed=7, T=cov.T)
             mx = SeirModel(cov, init, max_chains=Bx, device=local)
             sx = ChainSampler(mx, MCMC_CONFIG, Bx, seed=a.seed, first_chain_id=0, trace_capacity=40,
