@@ -74,6 +74,7 @@ __device__ __forceinline__ void move_copy(Move *dst, const Move *src, int t0) {
     if (i >= 0 && i < MOVE_DW) reinterpret_cast<int *>(dst)[i] = reinterpret_cast<const int *>(src)[i];
 }
 
+constexpr int TAIL_STRIDE = 16;       // 64-bit words between two chains' ticket counters
 constexpr int NMVTR = 2 + 4 * MMAX;   // is_accepted, target_log_prob, m[], t[], delta_t[], x_star[]
 
 struct PairNote;
@@ -85,6 +86,10 @@ struct Chains {
     Move *mvfix;                                         // [2][B] E->I-type proposal re-drawn after a row conflict (k_move_pair)
     unsigned *hand;                                      // [B] k_move_pair: token of the launch whose role 1 has its totals
     unsigned *late;                                      // [B] k_move_pair: launches whose role 0 gave up waiting for a speculative role
+                                                         //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
+    unsigned long long *tail;                            // [B][TAIL_STRIDE] k_se_chunk: tiles of the chain that have arrived, over all
+                                                         //     launches -- one counter per 128-byte line: eight chains' counters in
+                                                         //     one line made every ticket a cross-XCD transaction (+14 us per launch)
     unsigned *hand2;                                     // [B] the same token for role 2 (pre-drawn S->E-type proposal)
     Move *mvs;                                           // [2][B] S->E-type proposal pre-drawn for the next launch (k_move_pair, role 2)
     double *DownS;                                       // [2][B][2] its own-rows log-ratio {theta, const}
@@ -771,17 +776,24 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
 // ---------------------------------------------------------------------------------------------
 // NTC: the number of 64-day chunks at compile time (0 = any, loops stay rolled).  The kernel is one
 // wave of straight-line code executed once, so its cost is its instruction count.
-template <int NTC>
-__global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par) {
+// COH: the partial sums read here (Kpart, TS, Rpart, Ppart) were written by OTHER workgroups of the SAME launch
+// (k_se_chunk below) -- they are read past the L1 (agent-scope loads); see k_se_chunk for why that is enough.
+// bx: chunk role (T-chunks first), b: chain; executed by one wave (threadIdx.x < 64).
+// wait(): called once, after every load that does not depend on this launch's partial sums has been issued and
+// before the first one that does (k_se_chunk: the spin on the chain's tile counter goes there, so those loads and
+// the wait overlap); a no-op in k_hmc_chunk.
+template <int NTC, bool COH, typename Wait>
+__device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
+                                               const Chains &ch, int par, int bx, int b, Wait wait) {
     __shared__ double2 ltab[LOGTAB_N];
+    auto LDP = [](const double *p_) {
+        return COH ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_;
+    };
     constexpr int NC = NTC > 0 ? NTC : CT_MAXC;
     const int T = d.T, M = d.M, nmt = d.nmt;
     const int ntc = NTC > 0 ? NTC : d.ntc;
     const int ntile = nmt * ntc;
-    debug_skew(d);
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (d.aff_nb > 0) xcd_affine(blockIdx.x, ntc + d.Mp / WAVE, d.aff_nb, by, bx);
-    const int b = d.b0 + by, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp;
     const double *var = ch.var + (size_t)b * d.Pp;
     double *sc = w.scal + (size_t)b * NSCAL;
@@ -800,34 +812,10 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
         const double wd_t = c.wd[t];
         const double a0 = gr[5], g0 = gr[3], g1 = gr[4], pa0 = gr[11], pg0 = gr[9], pg1 = gr[10];
         const double va0 = var[5], vg0 = var[3], vg1 = var[4];
-        // column sums of this chunk
-        double col = 0.0;
-        {
-            const double *kp = w.Kpart + (size_t)b * nmt * d.Tp + t;
-            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-            for (int j0 = 0; j0 < nmt; j0 += 24) {
-                double x[24];
+        // V at the chunk ends, the chunk sums of the current position (chunk = lane)
+        double vend[NC];
 #pragma unroll
-                for (int j = 0; j < 24; ++j) x[j] = j0 + j < nmt ? kp[(size_t)(j0 + j) * d.Tp] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 24; j += 4) { c0 += x[j]; c1 += x[j + 1]; c2 += x[j + 2]; c3 += x[j + 3]; }
-            }
-            col = (c0 + c1) + (c2 + c3);
-        }
-        // tile scalars of row tile `lane` (and lane+64, ... when there are more), V at the chunk ends,
-        // the chunk sums of the current position (chunk = lane)
-        double bs[NC], as[NC], vend[NC];
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-            const bool on = cc < ntc && lane < nmt;
-            bs[cc] = on ? TS[((size_t)lane * ntc + cc) * 4] : 0.0;
-            as[cc] = on ? TS[((size_t)lane * ntc + cc) * 4 + 1] : 0.0;
-            vend[cc] = cc < ntc ? w.Vt[(size_t)b * d.Tp + cc * WAVE + WAVE - 1] : 0.0;
-        }
-        for (int r = lane + WAVE; r < nmt; r += WAVE)
-#pragma unroll
-            for (int cc = 0; cc < NC; ++cc)
-                if (cc < ntc) { bs[cc] += TS[((size_t)r * ntc + cc) * 4]; as[cc] += TS[((size_t)r * ntc + cc) * 4 + 1]; }
+        for (int cc = 0; cc < NC; ++cc) vend[cc] = cc < ntc ? w.Vt[(size_t)b * d.Tp + cc * WAVE + WAVE - 1] : 0.0;
         const double *ctr = w.CT + (((size_t)b * 2 + par) * CT_MAXC) * 4;
         const double cta_l = lane < ntc ? ctr[lane * 4] : 0.0, ctvp_l = lane < ntc ? ctr[lane * 4 + 1] : 0.0,
                      ctva_l = lane < ntc ? ctr[lane * 4 + 2] : 0.0;
@@ -836,6 +824,36 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
         const double *cgr = w.CG + (((size_t)b * 2 + par) * CT_MAXC) * 2;
         const double cg0_l = lane < ntc ? cgr[lane * 2] : 0.0, cg1_l = lane < ntc ? cgr[lane * 2 + 1] : 0.0;
         const double kir_t = t < T ? w.Kir[(size_t)b * d.Tp + t] : 0.0, dir_t = t < T ? w.Dir[(size_t)b * d.Tp + t] : 0.0;
+        wait();
+        // ---- from here on: this step's partial sums
+        // column sums of this chunk
+        double col = 0.0;
+        {
+            const double *kp = w.Kpart + (size_t)b * nmt * d.Tp + t;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+            // twelve loads in flight at a time (twenty-four cost 24 more registers, and the kernel that carries this role
+            // next to the gradient tile has to stay at five waves per SIMD); same order of additions as one batch of 24
+            for (int j0 = 0; j0 < nmt; j0 += 12) {
+                double x[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) x[j] = j0 + j < nmt ? LDP(kp + (size_t)(j0 + j) * d.Tp) : 0.0;
+#pragma unroll
+                for (int j = 0; j < 12; j += 4) { c0 += x[j]; c1 += x[j + 1]; c2 += x[j + 2]; c3 += x[j + 3]; }
+            }
+            col = (c0 + c1) + (c2 + c3);
+        }
+        // tile scalars of row tile `lane` (and lane+64, ... when there are more)
+        double bs[NC], as[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const bool on = cc < ntc && lane < nmt;
+            bs[cc] = on ? LDP(TS + ((size_t)lane * ntc + cc) * 4) : 0.0;
+            as[cc] = on ? LDP(TS + ((size_t)lane * ntc + cc) * 4 + 1) : 0.0;
+        }
+        for (int r = lane + WAVE; r < nmt; r += WAVE)
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+                if (cc < ntc) { bs[cc] += LDP(TS + ((size_t)r * ntc + cc) * 4); as[cc] += LDP(TS + ((size_t)r * ntc + cc) * 4 + 1); }
         lds_barrier();                                     // ltab (single wave: orders the LDS writes)
         const double gg0 = wave_sum(cg0_l), gg1 = wave_sum(cg1_l);
         // Everything that couples the chunks is linear in the tile scalars, so each lane forms its
@@ -903,15 +921,6 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
         const double u0 = gr[0], u1 = gr[1], beta = gr[2], p0 = gr[6], p1 = gr[7], p2 = gr[8];
         const double psi = gr[12], sig = gr[13], s0 = gr[14], s1 = gr[15];
         const double v0 = var[0], v1 = var[1], v2 = var[2];
-        double R = 0.0;
-        {
-            const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (own ? m : 0);
-            double x[NC];
-#pragma unroll
-            for (int j = 0; j < NC; ++j) x[j] = (own && j < ntc) ? rp[(size_t)j * d.Mp] : 0.0;
-#pragma unroll
-            for (int j = 0; j < NC; ++j) R += x[j];
-        }
         double Qs = 0.0;                                   // (Q s)_m at the current position
         if (own) {
             if (c.qw > 0 && c.qw <= 8) {
@@ -931,37 +940,54 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
                 for (int e = c.Qrow[m]; e < c.Qrow[m + 1]; ++e) Qs += c.Qval[e] * spr[c.Qcol[e]];
             }
         }
-        double ps = 0.0, rl = 0.0, rs = 0.0;
         const bool rows_here = d.chunked == 1;             // small M: sum_m l_m R_m, sum_m s_m R_m from the row partials
+        constexpr int RPL = 8;                             // Mp <= 512: rows lane, lane+64, ...
+        double la_[RPL], sp_[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            const int mm = lane + k * WAVE;
+            const bool on = rows_here && mm < M;
+            la_[k] = on ? c.la[mm] : 0.0;
+            sp_[k] = on ? spr[mm] : 0.0;
+        }
+        wait();
+        // ---- from here on: this step's partial sums
+        double R = 0.0;
+        {
+            const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (own ? m : 0);
+            double x[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) x[j] = (own && j < ntc) ? LDP(rp + (size_t)j * d.Mp) : 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) R += x[j];
+        }
+        double ps = 0.0, rl = 0.0, rs = 0.0;
         for (int i0 = lane; i0 < ntile; i0 += 4 * WAVE) {
             double x[4], y[4], z[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = i0 + j * WAVE;
                 const bool on = i < ntile;
-                x[j] = on ? w.Ppart[(size_t)b * ntile + i] : 0.0;
-                y[j] = (on && !rows_here) ? TS[(size_t)i * 4 + 2] : 0.0;
-                z[j] = (on && !rows_here) ? TS[(size_t)i * 4 + 3] : 0.0;
+                x[j] = on ? LDP(w.Ppart + (size_t)b * ntile + i) : 0.0;
+                y[j] = (on && !rows_here) ? LDP(TS + (size_t)i * 4 + 2) : 0.0;
+                z[j] = (on && !rows_here) ? LDP(TS + (size_t)i * 4 + 3) : 0.0;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ps += x[j]; rl += y[j]; rs += z[j]; }
         }
         if (rows_here) {
-            // Mp <= 512: rows lane, lane+64, ...: ntc partials each, one batch of loads
-            constexpr int RPL = 8;
-            double la_[RPL], sp_[RPL], Rr[RPL];
-#pragma unroll
+            // ntc partials per row, one batch of loads
+            double Rr[RPL];
+#pragma unroll 4
             for (int k = 0; k < RPL; ++k) {
                 const int mm = lane + k * WAVE;
                 const bool on = mm < M;
-                la_[k] = on ? c.la[mm] : 0.0;
-                sp_[k] = on ? spr[mm] : 0.0;
                 double acc = 0.0;
                 if (on) {
                     const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + mm;
                     double x[NC];
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) x[j] = j < ntc ? rp[(size_t)j * d.Mp] : 0.0;
+                    for (int j = 0; j < NC; ++j) x[j] = j < ntc ? LDP(rp + (size_t)j * d.Mp) : 0.0;
 #pragma unroll
                     for (int j = 0; j < NC; ++j) acc += x[j];
                 }
@@ -996,6 +1022,72 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
             sc[SC_PSI] = psin; sc[SC_SIG] = sign; sc[SC_BETA] = betan; sc[SC_S0] = s0n; sc[SC_S1] = s1n;
         }
     }
+}
+
+
+template <int NTC>
+__global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par) {
+    debug_skew(d);
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (d.aff_nb > 0) xcd_affine(blockIdx.x, (NTC > 0 ? NTC : d.ntc) + d.Mp / WAVE, d.aff_nb, by, bx);
+    hmc_chunk_role<NTC, false>(d, c, w, s, ch, par, bx, d.b0 + by, [] {});
+}
+
+// k_se_chunk: the gradient tiles of a leapfrog step AND the chunk roles of that step in one launch -- what it saves is
+// the chunk kernel's launch ramp and boundary (~2.5 us, fifteen times per sweep) and, because a role issues every
+// load that does not depend on the tiles while they are still running, most of its memory latency as well.
+// Grid: the XCD-affine tile grid of k_se (ntile x 8 blocks) followed by (ntc + Mp/64) x 8 role blocks (block id mod 8 =
+// chain there too).  A tile workgroup evaluates its tile exactly as k_se does and then counts itself in on the chain's
+// counter (Chains::tail, one cache line per chain); a role workgroup (one wave) issues its independent loads, waits
+// until the counter shows `target` -- every tile of the chain, of every launch so far -- and runs the role.  Blocks
+// are dispatched in id order, so a role is placed only after every tile has been: it can never hold a slot that an
+// unplaced tile needs, whatever the residency.
+// Memory: the hand-off uses NO agent-scope release/acquire (an L2 write-back / invalidate costs 7-30 us here,
+// tools/probes/xcd_barrier_probe.hip).  It relies on all workgroups of a chain sharing one XCD and hence one L2 --
+// block ids congruent mod 8, checked at sampler creation through XCC_ID (k_xcc_probe); the host uses this kernel
+// only then.  A tile's stores are acknowledged by that L2 (s_waitcnt vmcnt(0) in __syncthreads) before it counts
+// itself in, and the roles read the partial sums past their L1.  The roles write the NEXT position's tables (ea,
+// eb, psi ...) only after every tile of the chain has counted in, i.e. has long read the current ones.  Results are
+// bit-identical to k_se followed by k_hmc_chunk.
+template <int TSM, int NTC>
+#ifdef TAIL_X_OCC5
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+#else
+__global__ __launch_bounds__(256)
+#endif
+void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsigned long long target) {
+    const int ntile = d.ntc * d.nmt, n_tiles = ntile * d.aff_nb;
+    if ((int)blockIdx.x < n_tiles) {
+        int bz, tile;
+        xcd_affine(blockIdx.x, ntile, d.aff_nb, bz, tile);
+        se_tile<true, 1, TSM>(d, c, w, tile % d.ntc, tile / d.ntc, bz);
+        __syncthreads();                               // vmcnt(0): this tile's partial sums are in the XCD's L2
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_add(ch.tail + (size_t)(d.b0 + bz) * TAIL_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (threadIdx.x >= WAVE) return;                   // a role is one wave
+    const int L = (int)blockIdx.x - n_tiles;
+    const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
+    const unsigned long long *cnt = ch.tail + (size_t)b * TAIL_STRIDE;
+    hmc_chunk_role<NTC, true>(d, c, w, s, ch, par, role, b, [&] {
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) {                 // ~0.1 s: never seen; counted like k_move_pair's time-outs, no hang
+                if (threadIdx.x == 0) ch.late[b] += 1;
+                break;
+            }
+        }
+    });
+}
+
+// XCC_ID of every workgroup of a grid laid out like the XCD-affine grids: the host checks that blocks with the same
+// id mod 8 share an XCD before it uses k_se_chunk.
+__global__ void k_xcc_probe(unsigned *out) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) out[blockIdx.x] = v & 0xfu;
 }
 
 // Parameter tables + full parameter-dependent log-prob for the current state

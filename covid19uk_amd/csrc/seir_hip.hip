@@ -838,6 +838,9 @@ struct seir_sampler {
     bool copy_pending = false;
     bool use_graph = false;       // seir_sampler_desc::use_graph
     bool hmc_chunked = true;      // hmc_mode 1: every leapfrog step by the single-workgroup kernel
+    bool hmc_tail = true;         // hmc_mode 0: chunk roles inside the gradient launch (k_se_chunk) where xcd_local holds
+    bool xcd_local = false;       // blocks with the same id mod 8 share an XCD (k_xcc_probe at creation)
+    unsigned long long tail_count = 0;   // tiles per chain counted in by all k_se_chunk launches so far (Chains::tail)
     int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
     int moves_mode = 0;           // 0 = paired launches (k_move_pair) with the S->E-type proposal pre-drawn one launch ahead;
                                   // 1 = one proposal kernel per update (k_move_pa2); 2 = paired launches without the pre-draw
@@ -898,8 +901,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
     if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
-    if (ds->moves_mode < 0 || ds->moves_mode > 2 || ds->hmc_mode < 0 || ds->hmc_mode > 1)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..2, hmc_mode 0 or 1");
+    if (ds->moves_mode < 0 || ds->moves_mode > 2 || ds->hmc_mode < 0 || ds->hmc_mode > 2)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..2, hmc_mode 0..2");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
@@ -922,7 +925,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     // kernels of ~10 us) stays ahead either way.  Default: stream launches; seir_sampler_desc::use_graph selects the graph.
     s->use_graph = ds->use_graph != 0;
     s->pair_debug = ds->debug_pair;
-    s->hmc_chunked = ds->hmc_mode == 0;
+    s->hmc_chunked = ds->hmc_mode != 1;
+    s->hmc_tail = ds->hmc_mode == 0;
     s->moves_mode = ds->moves_mode;
     c.disable_mask = ds->disable_mask;
     {
@@ -960,6 +964,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.mvsel, (size_t)2 * B);
     S_ALLOC(ch.hand, (size_t)B);
     S_ALLOC(ch.late, (size_t)B);
+    S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE);
     S_ALLOC(ch.hand2, (size_t)B);
     S_ALLOC(ch.mvs, (size_t)2 * B);
     S_ALLOC(ch.DownS, (size_t)2 * B * 2);
@@ -996,10 +1001,31 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         }
         if (e != hipSuccess) rc = fail(SEIR_ERR_DEVICE, "sampler stream setup failed: %s", hipGetErrorString(e));
     }
+    if (!rc && s->hmc_tail) {
+        // Do blocks with the same id mod 8 share an XCD here?  k_se_chunk hands data between the workgroups of a chain
+        // through that XCD's L2 alone; it is used only if every workgroup of a grid shaped like its own says so.
+        const int nblk = 8 * 144;
+        unsigned *xcc = nullptr;
+        std::vector<unsigned> host(nblk, 99u);
+        hipError_t e = hipMalloc((void **)&xcc, nblk * sizeof(unsigned));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_xcc_probe, dim3(nblk), dim3(256), 0, ctx->stream, xcc);
+            e = hipMemcpyAsync(host.data(), xcc, nblk * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(xcc);
+        }
+        bool ok = e == hipSuccess;
+        for (int L = 8; L < nblk && ok; ++L) ok = host[L] == host[L & 7] && host[L] < 16u;
+        for (int a = 0; a < 8 && ok; ++a)
+            for (int b2 = a + 1; b2 < 8; ++b2) ok = ok && host[a] != host[b2];      // eight different XCDs
+        s->xcd_local = ok;
+    }
     if (rc) { seir_sampler_destroy(s); return rc; }
     *out = s;
     return 0;
 }
+
+extern "C" int seir_sampler_xcd_local(seir_sampler *s) { return (s && s->xcd_local) ? 1 : 0; }
 
 static int sampler_check(seir_sampler *s) {
     if (!s) return fail(SEIR_ERR_INVALID, "null sampler");
@@ -1246,8 +1272,29 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const int per = d0.ntc + d0.Mp / WAVE;
         const bool aff = (l.affinity & 1) && xcd_affinity_applies(per, nb);
         int par = 0;
+        // chunk roles inside the gradient launch (k_se_chunk): 8 chains, one XCD each (checked at creation), the
+        // XCD-affine grid, no graph capture in progress (the ticket counter does not care, but keep the two apart)
+        const int ntile_se = d0.ntc * d0.nmt;
+        const bool tail = s->hmc_tail && s->xcd_local && nb == 8 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nb) &&
+                          !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && ts_mode != 0;
         for (int i = 1; i < c.L; ++i) {
             l.d.sp_par = par;
+            if (tail) {
+                Dims df = l.d;
+                df.aff_nb = nb;
+                const dim3 gf((unsigned)((ntile_se + per) * nb));      // tiles, then the chunk roles
+                s->tail_count += (unsigned long long)ntile_se;         // what a chain's counter shows once this launch's tiles are in
+                const unsigned long long target = s->tail_count;
+#define LAUNCH_TAIL(TSM_, NTC_) hipLaunchKernelGGL((k_se_chunk<TSM_, NTC_>), gf, dim3(256), 0, st, df, ctx->c, ctx->w, c, s->ch, par, target)
+                if (ts_mode == 1) {
+                    if (d0.ntc == 1) LAUNCH_TAIL(1, 1); else if (d0.ntc == 6) LAUNCH_TAIL(1, 6); else LAUNCH_TAIL(1, 12);
+                } else {
+                    if (d0.ntc == 1) LAUNCH_TAIL(2, 1); else if (d0.ntc == 6) LAUNCH_TAIL(2, 6); else LAUNCH_TAIL(2, 12);
+                }
+#undef LAUNCH_TAIL
+                par ^= 1;
+                continue;
+            }
             launch_se<1>(ctx, l, true);
             Dims dc = l.d;
             dc.aff_nb = aff ? nb : 0;

@@ -190,8 +190,12 @@ typedef struct {
                                        pre-drawn one launch ahead; 1: one proposal kernel per update (k_move_pa2)
                                        -- kept as a cross-check; 2: paired launches without the pre-draw.
                                        Same draws in all three */
-    int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks (k_hmc_chunk); 1: every step
-                                       by the single-workgroup kernel -- same draws up to summation order */
+    int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks, run by the last workgroups of the
+                                       gradient launch itself (k_se_chunk) when all of a chain's workgroups share
+                                       an XCD (8 chains per launch, checked through XCC_ID at creation), otherwise
+                                       as their own launch (k_hmc_chunk); 1: every step by the single-workgroup
+                                       kernel; 2: chunks always as their own launch (the cross-check of 0: same
+                                       bits).  0/2 against 1: same draws up to summation order */
     int32_t use_graph;              /* 1: replay the sweep as a captured hipGraph (default: stream launches) */
     int32_t chain_groups;           /* chains split over this many streams (0 or 1: one stream) */
     int32_t disable_mask;           /* bit 0: HMC update, bits 1..4: S->E move, E->I move, S->E occult, E->I
@@ -265,6 +269,10 @@ int seir_host_free(void *host_ptr);
  * num_leapfrog_steps+1 times per sweep -- replayed `iters` times on the current
  * chain state (it only writes its partial-sum buffers). */
 int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms);
+
+/* 1 if the context's GPU places workgroups whose ids are congruent mod 8 on one XCD each (XCC_ID of a probe grid at
+ * creation): the condition under which hmc_mode 0 runs the chunk roles inside the gradient launch. */
+int seir_sampler_xcd_local(seir_sampler *s);
 
 /* Number of k_move_pair launches per chain in which the authoritative workgroup gave up waiting for
  * the speculative one (it then re-draws the proposal itself: results are unaffected, throughput is

@@ -505,3 +505,37 @@ def test_compact_event_trace_is_lossless_and_guards_its_range(api):
             s.set_kernel(step_size=1e-6)
             with pytest.raises(_lib.SeirError, match="65535"):
                 s.sample(1)
+
+
+@pytest.mark.gpu
+def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api):
+    """hmc="chunk" with 8 chains runs the chunk roles of a leapfrog step inside the gradient launch (k_se_chunk: the
+    last workgroups of a chain to arrive take the roles; hand-off through the XCD's L2) when the GPU places block ids
+    congruent mod 8 on one XCD each; hmc="chunk-split" launches them separately.  Same arithmetic in the same order:
+    every traced quantity must agree to the last bit, with and without workgroup skew."""
+    case = H.build_case("ni11", 31)
+    B = 8
+    u = synth.jitter_params(case["u"], B, scale=0.01, seed=3, T=case["k"].T)
+    ev = np.stack([case["events"]] * B)
+    cfg = dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=2)
+    out = {}
+    for mode, skew in (("chunk-split", 0), ("chunk", 0), ("chunk", 2)):
+        with api[0](case["cov"], case["init"], max_chains=B) as model:
+            model.set_option(debug_skew=skew)
+            with api[1](model, cfg, B, seed=77, trace_capacity=40, hmc=mode) as s:
+                if mode == "chunk" and not s.xcd_local():
+                    pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the fused form is not used")
+                s.set_state(u, ev)
+                s.set_kernel(step_size=0.02)
+                s.set_adaptation(adapt_step_size=True, num_adaptation_steps=20)
+                s.run(40)
+                tr = s.read_trace(40)
+                assert not s.pair_timeouts().any()
+                out[(mode, skew)] = tr
+    ref = out[("chunk-split", 0)]
+    for key in (("chunk", 0), ("chunk", 2)):
+        got = out[key]
+        assert np.array_equal(ref.theta, got.theta), key
+        assert np.array_equal(ref.events, got.events), key
+        for k in ref.hmc:
+            assert np.array_equal(ref.hmc[k], got.hmc[k]), (key, k)
