@@ -1117,10 +1117,151 @@ static_assert(sizeof(PairNote) == (2 + MMAX) * sizeof(int), "k_move_pair writes 
 //     is a row of a conflict, which role 0 detects on its own -- and the planes' row/range totals, fetched
 //     at entry: role 0 does not write anything before roles 1 and 2 hold them (one-word handshakes,
 //     Chains::hand / hand2; if a role is not there in time role 0 goes on and discards its output).
+// ---------------------------------------------------------------------------------------------
+// Band workgroups of k_move_pair (nband > 0): k_move_delta's work inside the pair launch.  The launch then carries
+// the whole MH step of the E->I-type proposal except its accept test, and the ten k_move_delta launches of a sweep
+// (7.7 us each, 2.5 of them launch ramp and boundary) are gone.  A band workgroup (8 waves, rows bx*rpb ..) waits
+// for the authoritative role's done-token (the proposal is certified, Chains::mvsel says which descriptor stands,
+// Chains::fpend is this launch's), evaluates the band part of the log-ratio over its rows with the F band of the
+// update accepted in this launch added ON THE FLY (as the roles do), writes its partial sums, then waits for the
+// speculative roles' tokens -- nobody reads F any more -- and applies that F band to its rows.
+// Hand-off as in k_se_chunk: XCD-local (tokens in the chain's own cache line, stores acknowledged by the shared L2
+// before a token is written, everything another workgroup of this launch may have written is read past the L1), no
+// agent-scope fence; the host launches band workgroups only where the XCC_ID probe allows it.  Band workgroups have
+// the highest block ids: they are placed after every role, so a waiting one never holds a slot a role needs.
+// ---------------------------------------------------------------------------------------------
+template <typename TT>
+__device__ __forceinline__ TT ld_l2(const TT *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void move_copy_l2(Move *dst, const Move *src, int t0) {
+    const int i = (int)threadIdx.x - t0;
+    if (i >= 0 && i < MOVE_DW) reinterpret_cast<int *>(dst)[i] = ld_l2(reinterpret_cast<const int *>(src) + i);
+}
+__device__ __forceinline__ void wait_token(const unsigned *p_, unsigned token, unsigned *late) {
+    int spins = 0;
+    while (ld_l2(p_) != token) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { *late += 1; break; }       // ~0.1 s: never seen; counted, no hang
+    }
+}
+__device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
+                                                const Chains &ch, int b, int bx, int nband, unsigned token, bool has_r1,
+                                                bool has_r2, int buf) {
+    __shared__ Move mvA, mvB, fp;
+    __shared__ int mv_sel;
+    __shared__ double sh_th[MVW], sh_cn[MVW];
+    __shared__ double2 ltab[LDSTAB_N];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
+    const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];      // constant during the event updates
+    const unsigned *done = ch.done + (size_t)b * 2 * TAIL_STRIDE;
+    if (tid == 0) {
+        wait_token(done + 0, token, ch.late + b);
+        // the speculative role publishes its descriptor (token 3) well before it is done (token 1): the authoritative role
+        // certifies that proposal from the row totals alone and may finish before the descriptor is even written
+        if (has_r1) wait_token(done + 3, token, ch.late + b);
+    }
+    __syncthreads();
+    move_copy_l2(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
+    move_copy_l2(&mvB, ch.mvfix + (size_t)buf * s.B + b, 64);
+    move_copy_l2(&fp, ch.fpend + b, 128);
+    if (tid == 192) mv_sel = ld_l2(ch.mvsel + (size_t)buf * s.B + b);
+    __syncthreads();
+    const Move &mv = mv_sel ? mvB : mvA;
+    const bool has_fp = fp.valid == 1;
+    const int rpb = (d.M + nband - 1) / nband;
+    const int r_lo = bx * rpb, r_hi = min(d.M, r_lo + rpb);
+    double dth = 0.0;
+    if (mv.valid && mv.n > 0 && mv.any_dI) {
+        // a wave's two rows (rpb <= 16 = 2 MVW) side by side: the coefficients of both, then per 64-day piece of the hull
+        // the loads of both before any arithmetic -- half the dependent round trips of one row after the other
+        const double *ea = w.ea + (size_t)b * d.Tp;
+        constexpr int NR = 2;
+        int jr[NR];
+        bool on[NR];
+        double eb[NR], coef[NR][MMAX], cfp[NR][MMAX];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            jr[r] = r_lo + wave + r * MVW;
+            bool mine = false;
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == jr[r]);
+            on[r] = jr[r] < r_hi && !mine;           // wave-uniform: the updated rows' part is the drawing role's (Chains::Down)
+            const int j = on[r] ? jr[r] : r_lo;
+            eb[r] = w.eb[(size_t)b * d.Mp + j];
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i) {
+                coef[r][i] = (on[r] && i < mv.n) ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i]) : 0.0;
+                cfp[r][i] = (on[r] && has_fp && i < fp.n) ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+            }
+        }
+        for (int t0 = mv.LO; t0 <= mv.HI; t0 += WAVE) {
+            const int t = t0 + lane;
+            double dF[NR], S[NR], I[NR], kse[NR], F[NR];
+            bool act[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                dF[r] = 0.0;
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF[r] += coef[r][i];
+                act[r] = on[r] && t <= mv.HI && dF[r] != 0.0;
+                const size_t q = ((size_t)b * d.Mp + (on[r] ? jr[r] : r_lo)) * d.Tp + (act[r] ? t : mv.LO);
+                S[r] = (double)ld_l2(w.St[0] + q); I[r] = (double)ld_l2(w.St[2] + q);
+                kse[r] = (double)ld_l2(w.K[0] + q); F[r] = ld_l2(w.F + q);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (!act[r]) continue;
+                if (has_fp) {                          // summed first, as apply_f_band does
+                    double dFp = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MMAX; ++i)
+                        if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfp[r][i];
+                    if (dFp != 0.0) F[r] += dFp;
+                }
+                dth += band_delta(S[r], I[r], kse[r], F[r], dF[r], ea[t] * eb[r], psi * c.W[t], d.rate_floor * d.dt, d.dt, ltab);
+            }
+        }
+    }
+    dth = wave_sum(dth);
+    if (lane == 0) sh_th[wave] = dth;
+    __syncthreads();
+    if (tid == 0) {
+        double *out = ch.Dpart + ((size_t)b * nband + bx) * 2;
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < MVW; ++k) a += sh_th[k];
+        out[0] = a;
+        out[1] = 0.0;
+        // the F band: once nobody reads F any more
+        if (has_fp) {
+            if (has_r1) wait_token(done + 1, token, ch.late + b);
+            if (has_r2) wait_token(done + 2, token, ch.late + b);
+        }
+    }
+    if (!has_fp) return;
+    __syncthreads();
+    for (int j = r_lo + wave; j < r_hi; j += MVW) {
+        double cfp[MMAX];
+#pragma unroll
+        for (int i = 0; i < MMAX; ++i)
+            cfp[i] = i < fp.n ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+        double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
+        for (int t = fp.LO + lane; t <= fp.HI; t += WAVE) {
+            double dFp = 0.0;
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfp[i];
+            if (dFp != 0.0) Fr[t] = ld_l2(Fr + t) + dFp;
+        }
+    }
+    (void)sh_cn;
+}
+
 template <bool WF>
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
                                                    MoveSpec next, MoveSpec se_next, int have_prev, int have_pre,
-                                                   int pbuf, int nbk, int lidx, int dbg) {
+                                                   int pbuf, int nbk, int lidx, int dbg, int nband) {
     extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
@@ -1132,9 +1273,15 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     // block id = slot * nbk + chain with the speculative roles in the low slots: they are dispatched first,
     // so an authoritative workgroup never holds a CU waiting for a partner that has not been placed yet,
     // whatever the number of chains; the closing launch has role 0 only
-    const int nroles = (int)gridDim.x / nbk, slot = (int)blockIdx.x / nbk;
-    const int role = slot == nroles - 1 ? 0 : slot + 1;
+    const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;
     const int b = d.b0 + (int)blockIdx.x - slot * nbk, tid = threadIdx.x;
+    if (slot >= nroles) {                                  // band workgroups (the highest block ids)
+        const unsigned tok = ch.sweep[b] * 64u + (unsigned)lidx + 1u;
+        const bool r1 = next.kind >= 0 && nroles >= 2, r2 = se_next.kind >= 0 && nroles == 3;
+        pair_band_block(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1);
+        return;
+    }
+    const int role = slot == nroles - 1 ? 0 : slot + 1;
     const int M = d.M, T = d.T;
     const bool do_se = role == 0 && se.kind >= 0, do_nx = next.kind >= 0, do_pre = se_next.kind >= 0 && nroles == 3;
     if (role == 1 && !do_nx) return;
@@ -1243,6 +1390,12 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         RSTAMP(10);
         Move *out = (role == 1 ? ch.mv : ch.mvs) + (size_t)(pbuf ^ 1) * s.B + b;
         move_copy(out, &sm_nx.mv, MVB - WAVE);             // by the last wave: nobody's loads queue behind the store
+        if (nband > 0 && role == 1 && tid >= MVB - WAVE) {
+            // band workgroups start from this descriptor while the log-ratio over the updated rows is still being evaluated
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == MVB - WAVE)
+                __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 3, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // ... and its log-ratio over the rows it updates (for role 1, k_move_delta then does the band only); the F
         // band of an accepted pending update is not in F yet and is added on the fly
         const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
@@ -1250,6 +1403,11 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
                                : ch.DownS + ((size_t)(pbuf ^ 1) * s.B + b) * 2;
         mv_own_rows_to_down(d, c, w, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred, od);
         RSTAMP(11);
+        if (nband > 0) {                                   // band workgroups: this role reads F no more, its output is in L2
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + role, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     if (!have_prev && tid == 64) ch.fpend[b].valid = 0;    // first launch of a sweep: nothing pending
@@ -1409,6 +1567,11 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         nt[1] = nrows;                                                          // PairNote::n
 #pragma unroll
         for (int j = 0; j < MMAX; ++j) nt[2 + j] = j < nrows ? pendp->m[j] : -1;   // PairNote::rows
+    }
+    if (nband > 0) {                                       // band workgroups may go: descriptors, mvsel and fpend are in L2
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 0, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -87,6 +87,8 @@ struct Chains {
     unsigned *hand;                                      // [B] k_move_pair: token of the launch whose role 1 has its totals
     unsigned *late;                                      // [B] k_move_pair: launches whose role 0 gave up waiting for a speculative role
                                                          //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
+    unsigned *done;                                      // [B][2 TAIL_STRIDE] k_move_pair with band workgroups: token of the launch whose
+                                                         //     role r has finished, at [b][r] (a chain's three tokens in its own line)
     unsigned long long *tail;                            // [B][TAIL_STRIDE] k_se_chunk: tiles of the chain that have arrived, over all
                                                          //     launches -- one counter per 128-byte line: eight chains' counters in
                                                          //     one line made every ticket a cross-XCD transaction (+14 us per launch)

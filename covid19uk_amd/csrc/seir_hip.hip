@@ -842,7 +842,8 @@ struct seir_sampler {
     bool xcd_local = false;       // blocks with the same id mod 8 share an XCD (k_xcc_probe at creation)
     unsigned long long tail_count = 0;   // tiles per chain counted in by all k_se_chunk launches so far (Chains::tail)
     int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
-    int moves_mode = 0;           // 0 = paired launches (k_move_pair) with the S->E-type proposal pre-drawn one launch ahead;
+    int moves_mode = 0;           // 0 = paired launches (k_move_pair) with the S->E-type proposal pre-drawn one launch ahead (3: the same,
+                                  //     never with band workgroups in the pair launch);
                                   // 1 = one proposal kernel per update (k_move_pa2); 2 = paired launches without the pre-draw
     int graph_skew = 0, graph_aff = 3;   // context options the captured graph was built with
     bool have_state = false;
@@ -901,8 +902,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
     if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
-    if (ds->moves_mode < 0 || ds->moves_mode > 2 || ds->hmc_mode < 0 || ds->hmc_mode > 2)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..2, hmc_mode 0..2");
+    if (ds->moves_mode < 0 || ds->moves_mode > 3 || ds->hmc_mode < 0 || ds->hmc_mode > 2)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..3, hmc_mode 0..2");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
@@ -965,6 +966,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.hand, (size_t)B);
     S_ALLOC(ch.late, (size_t)B);
     S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE);
+    S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
     S_ALLOC(ch.hand2, (size_t)B);
     S_ALLOC(ch.mvs, (size_t)2 * B);
     S_ALLOC(ch.DownS, (size_t)2 * B * 2);
@@ -1001,7 +1003,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         }
         if (e != hipSuccess) rc = fail(SEIR_ERR_DEVICE, "sampler stream setup failed: %s", hipGetErrorString(e));
     }
-    if (!rc && s->hmc_tail) {
+    if (!rc && (s->hmc_tail || s->moves_mode == 0 || s->moves_mode == 2)) {
         // Do blocks with the same id mod 8 share an XCD here?  k_se_chunk hands data between the workgroups of a chain
         // through that XCD's L2 alone; it is used only if every workgroup of a grid shaped like its own says so.
         const int nblk = 8 * 144;
@@ -1333,28 +1335,39 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         if (s->moves_mode != 1 && c.n_scans > 30) s->moves_mode = 1;   // k_move_pair's launch tokens cover 62 launches per sweep
         if (s->moves_mode != 1) {
             // paired form: [finalize pending E->I-type | whole S->E-type update | propose E->I-type], then
-            // the log-ratio of the E->I-type proposal over its band: 4 launches per scan
+            // the log-ratio of the E->I-type proposal over its band: 4 launches per scan -- or 2, with the band
+            // evaluated by more workgroups of the pair launch itself (XCD-local hand-off, see pair_band_block): 8
+            // chains on one stream, one XCD each (checked at creation), every workgroup resident at once
             const int npairs = 2 * c.n_scans;
             int have_pre = 0;
+            int cus = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            const int nband_fit = (d.M + 15) / 16;                      // 16 rows per band workgroup: two per wave
+            const bool band_in_pair = s->moves_mode != 3 && s->xcd_local && nb == 8 && s->ngroups == 1 && !s->use_graph &&
+                                      (3 + nband_fit) * nb <= cus;
+            const int nband = band_in_pair ? nband_fit : 0;
+            SamplerCfg cp = c;
+            if (band_in_pair) cp.nrb_d = nband;                          // the band's partial sums: one pair per band workgroup
             for (int scan = 0; scan < c.n_scans; ++scan)
                 for (int half = 0; half < 2; ++half) {
                     const int pair = 2 * scan + half;
                     const MoveSpec se{half, 0, 2 * half, scan}, nx{half, 1, 2 * half + 1, scan};
                     // a third role pre-draws the S->E-type proposal of the next pair (same sweep)
-                    const bool pre = s->moves_mode == 0 && pair + 1 < npairs;
+                    const bool pre = (s->moves_mode == 0 || s->moves_mode == 3) && pair + 1 < npairs;
                     const int nh = (half + 1) & 1, nscan = scan + (half == 1 ? 1 : 0);
                     const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : MoveSpec{-1, 0, 0, 0};
-                    hipLaunchKernelGGL(pair_fn, dim3((pre ? 3 : 2) * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch,
-                                       se, nx, se_next, have_prev, have_pre, pbuf, nb, pair, s->pair_debug);
+                    hipLaunchKernelGGL(pair_fn, dim3(((pre ? 3 : 2) + nband) * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, cp, s->ch,
+                                       se, nx, se_next, have_prev, have_pre, pbuf, nb, pair, s->pair_debug, nband);
                     have_pre = pre ? 1 : 0;
                     pbuf ^= 1;
-                    hipLaunchKernelGGL((k_move_delta<false>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
+                    if (!band_in_pair)
+                        hipLaunchKernelGGL((k_move_delta<false>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
                 }
             if (have_prev) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
-                hipLaunchKernelGGL(pair_fn, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, c, s->ch, none, close, none, 1,
-                                   0, pbuf, nb, 62, 0);
+                hipLaunchKernelGGL(pair_fn, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, cp, s->ch, none, close, none, 1,
+                                   0, pbuf, nb, 62, 0, 0);
                 // the F band of the last accepted E->I update: by k_record's waves when it runs anyway
                 if (s->record_events) fpend_in_record = 1;
                 else hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);

@@ -188,8 +188,11 @@ typedef struct {
     /* ---- ABI v2: launch form and test hooks; all-zero = the defaults ---------------------------- */
     int32_t moves_mode;             /* 0: paired event-update launches (k_move_pair) with the S->E-type proposal
                                        pre-drawn one launch ahead; 1: one proposal kernel per update (k_move_pa2)
-                                       -- kept as a cross-check; 2: paired launches without the pre-draw.
-                                       Same draws in all three */
+                                       -- kept as a cross-check; 2: paired launches without the pre-draw; 3: as 0 with
+                                       the band part of the E->I-type log-ratio always as its own launch
+                                       (k_move_delta).  0 and 2 let workgroups of the pair launch evaluate it where
+                                       all of a chain's workgroups share an XCD (8 chains, seir_sampler_xcd_local).
+                                       Same draws in all four */
     int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks, run by the last workgroups of the
                                        gradient launch itself (k_se_chunk) when all of a chain's workgroups share
                                        an XCD (8 chains per launch, checked through XCC_ID at creation), otherwise

@@ -539,3 +539,57 @@ def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api):
         assert np.array_equal(ref.events, got.events), key
         for k in ref.hmc:
             assert np.array_equal(ref.hmc[k], got.hmc[k]), (key, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg,eps", [("ni11", dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
+                                          ("uk380", dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5)])
+def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, cfg, eps):
+    """moves="paired" with 8 chains evaluates the band part of the E->I-type log-ratio with more workgroups of the
+    k_move_pair launch (pair_band_block: done-tokens and an XCD-local hand-off, the F band of the update accepted in
+    the launch added on the fly and applied once every role is done) where the GPU places block ids congruent mod 8
+    on one XCD each; moves="paired-delta" always launches k_move_delta for it.  The two sum the band's cells in a
+    different order (~1e-16 on a log-ratio): every integer draw and accept flag and the final state must be identical,
+    continuous quantities agree to 1e-12 -- with and without workgroup skew and with the speculative roles made late
+    (among themselves the in-pair runs must agree to the last bit)."""
+    case = H.build_case(name, 41)
+    B = 8
+    n = 30 if name == "ni11" else 12
+    u = synth.jitter_params(case["u"], B, scale=0.01 if name == "ni11" else 0.002, seed=5, T=case["k"].T)
+    ev = np.stack([case["events"]] * B)
+    out = {}
+    for mode, skew, dbg in (("paired-delta", 0, 0), ("paired", 0, 0), ("paired", 1, 0), ("paired", 0, 5)):
+        with api[0](case["cov"], case["init"], max_chains=B) as model:
+            model.set_option(debug_skew=skew)
+            with api[1](model, cfg, B, seed=91, trace_capacity=n, moves=mode, debug_pair=dbg) as s:
+                if mode == "paired" and not s.xcd_local():
+                    pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the fused form is not used")
+                s.set_state(u, ev)
+                s.set_kernel(step_size=eps)
+                s.run(n)
+                tr = s.read_trace(n)
+                if dbg == 0:
+                    assert not s.pair_timeouts().any()
+                out[(mode, skew, dbg)] = (tr, s.get_state())
+    ref, ref_state = out[("paired-delta", 0, 0)]
+    base, base_state = out[("paired", 0, 0)]
+    for key in (("paired", 0, 0), ("paired", 1, 0), ("paired", 0, 5)):
+        got, got_state = out[key]
+        assert np.array_equal(ref.events, got.events), key
+        np.testing.assert_allclose(got.theta, ref.theta, rtol=1e-12, atol=0.0, err_msg=str(key))
+        for k in ref.hmc:
+            np.testing.assert_allclose(got.hmc[k], ref.hmc[k], rtol=1e-12, atol=0.0, err_msg=str((key, k)))
+        for mk in ref.moves:
+            for k in ref.moves[mk]:
+                if k == "target_log_prob":
+                    np.testing.assert_allclose(got.moves[mk][k], ref.moves[mk][k], rtol=1e-12, atol=0.0, err_msg=str((key, mk)))
+                else:
+                    assert np.array_equal(ref.moves[mk][k], got.moves[mk][k]), (key, mk, k)
+        assert np.array_equal(ref_state[1], got_state[1]), key
+        np.testing.assert_allclose(got_state[2], ref_state[2], rtol=1e-12, atol=0.0)
+        # the in-pair runs among themselves: same code, same order
+        assert np.array_equal(base.theta, got.theta) and np.array_equal(base.events, got.events), key
+        for mk in base.moves:
+            for k in base.moves[mk]:
+                assert np.array_equal(base.moves[mk][k], got.moves[mk][k]), (key, mk, k)
+        assert np.array_equal(base_state[2], got_state[2]), key
