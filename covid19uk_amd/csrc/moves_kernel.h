@@ -1154,6 +1154,32 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
     const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];      // constant during the event updates
     const unsigned *done = ch.done + (size_t)b * 2 * TAIL_STRIDE;
+    const int rpb = (d.M + nband - 1) / nband;
+    const int r_lo = bx * rpb, r_hi = min(d.M, r_lo + rpb);
+    // ---- the update accepted in this launch (token 4, early in the authoritative role): its descriptor, and what its F
+    // band needs for this workgroup's rows -- coefficients and the F values themselves (nobody writes F but this code)
+    if (tid == 0) wait_token(done + 4, token, ch.late + b);
+    __syncthreads();
+    move_copy_l2(&fp, ch.fpend + b, 128);
+    __syncthreads();
+    const bool has_fp = fp.valid == 1;
+    constexpr int NRB = 2, NPF = 2;                    // rows per wave (rpb <= 16), 64-day pieces of a hull (dmax <= 127)
+    double cfb[NRB][MMAX], Fpre[NRB][NPF];
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) {
+        const int j = r_lo + wave + r * MVW;
+        const bool onr = has_fp && j < r_hi;
+#pragma unroll
+        for (int i = 0; i < MMAX; ++i)
+            cfb[r][i] = (onr && i < fp.n) ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int t = fp.LO + q * WAVE + lane;
+            Fpre[r][q] = (onr && t <= fp.HI) ? ld_l2(w.F + ((size_t)b * d.Mp + j) * d.Tp + t) : 0.0;
+        }
+    }
+    const bool pre_ok = !has_fp || fp.HI - fp.LO < NPF * WAVE;      // a longer hull (dmax > 127): the loop at the end reloads
+    // ---- the proposal to evaluate
     if (tid == 0) {
         wait_token(done + 0, token, ch.late + b);
         // the speculative role publishes its descriptor (token 3) well before it is done (token 1): the authoritative role
@@ -1163,13 +1189,9 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     __syncthreads();
     move_copy_l2(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
     move_copy_l2(&mvB, ch.mvfix + (size_t)buf * s.B + b, 64);
-    move_copy_l2(&fp, ch.fpend + b, 128);
     if (tid == 192) mv_sel = ld_l2(ch.mvsel + (size_t)buf * s.B + b);
     __syncthreads();
     const Move &mv = mv_sel ? mvB : mvA;
-    const bool has_fp = fp.valid == 1;
-    const int rpb = (d.M + nband - 1) / nband;
-    const int r_lo = bx * rpb, r_hi = min(d.M, r_lo + rpb);
     double dth = 0.0;
     if (mv.valid && mv.n > 0 && mv.any_dI) {
         // a wave's two rows (rpb <= 16 = 2 MVW) side by side: the coefficients of both, then per 64-day piece of the hull
@@ -1191,7 +1213,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
 #pragma unroll
             for (int i = 0; i < MMAX; ++i) {
                 coef[r][i] = (on[r] && i < mv.n) ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i]) : 0.0;
-                cfp[r][i] = (on[r] && has_fp && i < fp.n) ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+                cfp[r][i] = on[r] ? cfb[r][i] : 0.0;   // the accepted update's coefficients: prefetched above for the same rows
             }
         }
         for (int t0 = mv.LO; t0 <= mv.HI; t0 += WAVE) {
@@ -1241,18 +1263,29 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     }
     if (!has_fp) return;
     __syncthreads();
-    for (int j = r_lo + wave; j < r_hi; j += MVW) {
-        double cfp[MMAX];
 #pragma unroll
-        for (int i = 0; i < MMAX; ++i)
-            cfp[i] = i < fp.n ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+    for (int r = 0; r < NRB; ++r) {
+        const int j = r_lo + wave + r * MVW;
+        if (j >= r_hi) continue;
         double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
-        for (int t = fp.LO + lane; t <= fp.HI; t += WAVE) {
-            double dFp = 0.0;
+        if (pre_ok) {
 #pragma unroll
-            for (int i = 0; i < MMAX; ++i)
-                if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfp[i];
-            if (dFp != 0.0) Fr[t] = ld_l2(Fr + t) + dFp;
+            for (int q = 0; q < NPF; ++q) {
+                const int t = fp.LO + q * WAVE + lane;
+                double dFp = 0.0;
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfb[r][i];
+                if (t <= fp.HI && dFp != 0.0) Fr[t] = Fpre[r][q] + dFp;
+            }
+        } else {
+            for (int t = fp.LO + lane; t <= fp.HI; t += WAVE) {
+                double dFp = 0.0;
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfb[r][i];
+                if (dFp != 0.0) Fr[t] = ld_l2(Fr + t) + dFp;
+            }
         }
     }
     (void)sh_cn;
@@ -1410,7 +1443,13 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         }
         return;
     }
-    if (!have_prev && tid == 64) ch.fpend[b].valid = 0;    // first launch of a sweep: nothing pending
+    if (!have_prev && tid == 64) {                         // first launch of a sweep: nothing pending
+        ch.fpend[b].valid = 0;
+        if (nband > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 4, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // before the first store a speculative role could mistake for the state at entry: has it fetched its totals?
     // (bounded wait; normally the roles are long past that point when the accept test above is done)
     bool late = false, late2 = false;
@@ -1449,6 +1488,12 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         // the F values it reads.
         if (pend_acc && mv.any_dI) move_copy(ch.fpend + b, &mv, MVB - WAVE);     // mv.valid == 1: it was accepted
         else if (tid == MVB - WAVE) ch.fpend[b].valid = 0;
+        if (nband > 0 && tid >= MVB - WAVE) {
+            // band workgroups prefetch what the F band needs (token 4) long before the proposal they evaluate is certified
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == MVB - WAVE)
+                __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 4, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (pend_acc) mv_apply_rows(d, w, s, b, mv);
         if (tid == 0) {
             if (pend_acc) {
