@@ -1179,71 +1179,84 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
         }
     }
     const bool pre_ok = !has_fp || fp.HI - fp.LO < NPF * WAVE;      // a longer hull (dmax > 127): the loop at the end reloads
-    // ---- the proposal to evaluate
+    // ---- the proposal to evaluate.  The planes are final once the authoritative role has applied its own updates (token
+    // 5), a little before it has certified the speculative proposal; the band is evaluated for that proposal at once
+    // and, in the rare launch in which a row conflict made the authoritative role draw it again (Chains::mvsel, known
+    // with the last token), evaluated again for the re-drawn one.
     if (tid == 0) {
-        wait_token(done + 0, token, ch.late + b);
-        // the speculative role publishes its descriptor (token 3) well before it is done (token 1): the authoritative role
-        // certifies that proposal from the row totals alone and may finish before the descriptor is even written
+        wait_token(done + 5, token, ch.late + b);
+        // the speculative role publishes its descriptor (token 3) well before it is done (token 1)
         if (has_r1) wait_token(done + 3, token, ch.late + b);
     }
     __syncthreads();
     move_copy_l2(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
-    move_copy_l2(&mvB, ch.mvfix + (size_t)buf * s.B + b, 64);
-    if (tid == 192) mv_sel = ld_l2(ch.mvsel + (size_t)buf * s.B + b);
     __syncthreads();
-    const Move &mv = mv_sel ? mvB : mvA;
-    double dth = 0.0;
-    if (mv.valid && mv.n > 0 && mv.any_dI) {
-        // a wave's two rows (rpb <= 16 = 2 MVW) side by side: the coefficients of both, then per 64-day piece of the hull
-        // the loads of both before any arithmetic -- half the dependent round trips of one row after the other
-        const double *ea = w.ea + (size_t)b * d.Tp;
-        constexpr int NR = 2;
-        int jr[NR];
-        bool on[NR];
-        double eb[NR], coef[NR][MMAX], cfp[NR][MMAX];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            jr[r] = r_lo + wave + r * MVW;
-            bool mine = false;
-#pragma unroll
-            for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == jr[r]);
-            on[r] = jr[r] < r_hi && !mine;           // wave-uniform: the updated rows' part is the drawing role's (Chains::Down)
-            const int j = on[r] ? jr[r] : r_lo;
-            eb[r] = w.eb[(size_t)b * d.Mp + j];
-#pragma unroll
-            for (int i = 0; i < MMAX; ++i) {
-                coef[r][i] = (on[r] && i < mv.n) ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i]) : 0.0;
-                cfp[r][i] = on[r] ? cfb[r][i] : 0.0;   // the accepted update's coefficients: prefetched above for the same rows
-            }
-        }
-        for (int t0 = mv.LO; t0 <= mv.HI; t0 += WAVE) {
-            const int t = t0 + lane;
-            double dF[NR], S[NR], I[NR], kse[NR], F[NR];
-            bool act[NR];
-#pragma unroll
+    auto evaluate = [&](const Move &mv) -> double {
+        double dth = 0.0;
+        if (mv.valid && mv.n > 0 && mv.any_dI) {
+            // a wave's two rows (rpb <= 16 = 2 MVW) side by side: the coefficients of both, then per 64-day piece of the hull
+            // the loads of both before any arithmetic -- half the dependent round trips of one row after the other
+            const double *ea = w.ea + (size_t)b * d.Tp;
+            constexpr int NR = 2;
+            int jr[NR];
+            bool on[NR];
+            double eb[NR], coef[NR][MMAX], cfp[NR][MMAX];
+    #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                dF[r] = 0.0;
-#pragma unroll
-                for (int i = 0; i < MMAX; ++i)
-                    if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF[r] += coef[r][i];
-                act[r] = on[r] && t <= mv.HI && dF[r] != 0.0;
-                const size_t q = ((size_t)b * d.Mp + (on[r] ? jr[r] : r_lo)) * d.Tp + (act[r] ? t : mv.LO);
-                S[r] = (double)ld_l2(w.St[0] + q); I[r] = (double)ld_l2(w.St[2] + q);
-                kse[r] = (double)ld_l2(w.K[0] + q); F[r] = ld_l2(w.F + q);
-            }
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                if (!act[r]) continue;
-                if (has_fp) {                          // summed first, as apply_f_band does
-                    double dFp = 0.0;
-#pragma unroll
-                    for (int i = 0; i < MMAX; ++i)
-                        if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfp[r][i];
-                    if (dFp != 0.0) F[r] += dFp;
+                jr[r] = r_lo + wave + r * MVW;
+                bool mine = false;
+    #pragma unroll
+                for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == jr[r]);
+                on[r] = jr[r] < r_hi && !mine;           // wave-uniform: the updated rows' part is the drawing role's (Chains::Down)
+                const int j = on[r] ? jr[r] : r_lo;
+                eb[r] = w.eb[(size_t)b * d.Mp + j];
+    #pragma unroll
+                for (int i = 0; i < MMAX; ++i) {
+                    coef[r][i] = (on[r] && i < mv.n) ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i]) : 0.0;
+                    cfp[r][i] = on[r] ? cfb[r][i] : 0.0;   // the accepted update's coefficients: prefetched above for the same rows
                 }
-                dth += band_delta(S[r], I[r], kse[r], F[r], dF[r], ea[t] * eb[r], psi * c.W[t], d.rate_floor * d.dt, d.dt, ltab);
+            }
+            for (int t0 = mv.LO; t0 <= mv.HI; t0 += WAVE) {
+                const int t = t0 + lane;
+                double dF[NR], S[NR], I[NR], kse[NR], F[NR];
+                bool act[NR];
+    #pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    dF[r] = 0.0;
+    #pragma unroll
+                    for (int i = 0; i < MMAX; ++i)
+                        if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF[r] += coef[r][i];
+                    act[r] = on[r] && t <= mv.HI && dF[r] != 0.0;
+                    const size_t q = ((size_t)b * d.Mp + (on[r] ? jr[r] : r_lo)) * d.Tp + (act[r] ? t : mv.LO);
+                    S[r] = (double)ld_l2(w.St[0] + q); I[r] = (double)ld_l2(w.St[2] + q);
+                    kse[r] = (double)ld_l2(w.K[0] + q); F[r] = ld_l2(w.F + q);
+                }
+    #pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    if (!act[r]) continue;
+                    if (has_fp) {                          // summed first, as apply_f_band does
+                        double dFp = 0.0;
+    #pragma unroll
+                        for (int i = 0; i < MMAX; ++i)
+                            if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfp[r][i];
+                        if (dFp != 0.0) F[r] += dFp;
+                    }
+                    dth += band_delta(S[r], I[r], kse[r], F[r], dF[r], ea[t] * eb[r], psi * c.W[t], d.rate_floor * d.dt, d.dt, ltab);
+                }
             }
         }
+        return dth;
+    };
+    double dth = evaluate(mvA);
+    if (tid == 0) {
+        wait_token(done + 0, token, ch.late + b);
+        mv_sel = ld_l2(ch.mvsel + (size_t)buf * s.B + b);
+    }
+    __syncthreads();
+    if (mv_sel) {                                          // uniform, rare
+        move_copy_l2(&mvB, ch.mvfix + (size_t)buf * s.B + b, 64);
+        __syncthreads();
+        dth = evaluate(mvB);
     }
     dth = wave_sum(dth);
     if (lane == 0) sh_th[wave] = dth;
@@ -1565,6 +1578,9 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
             mv_trace(s, ch, b, mv, s_acc_se, tr_slot, hs_th + hs_cn);
         }
         __syncthreads();             // a re-drawn proposal in (3) must see the state written above
+        // band workgroups: the planes are final (token 5); which descriptor stands they learn from the last token
+        if (nband > 0 && tid == 0)
+            __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 5, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PSTAMP(5);
     }
     // ---- (3) certify role 1's proposal; closing launch: advance the sweep counter
