@@ -406,7 +406,8 @@ def main():
                        "sweep": "HMC(16 leapfrogs) + 5 x [S->E move, E->I move, S->E occult, E->I occult]",
                        "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] (uint16 counts) + kernel results per sweep",
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"kernel": "k_se<GRAD=true,SRC=planes> (S->E term + gradient sums, all chains)",
+            "roofline": {"kernel": "k_se<GRAD=true,SRC=planes> (S->E term + gradient sums, all chains; 17 gradient evaluations per sweep: "
+                                   "2 as this kernel, 15 as the tile phase of k_se_chunk, which then runs the leapfrog update in the same launch)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_uses": "algorithmic_bytes_per_launch (SURVEY.md 8d: fp64 events + Cstar once per launch)",
