@@ -1435,7 +1435,23 @@ extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
 }
 
 // 16-bit event trace: a count that did not fit was truncated on the device -- fail loudly
+// A hand-off inside a launch that timed out (k_move_pair's handshakes and band tokens, k_se_chunk's tile counter) means
+// a workgroup went on without what it waited for: never seen outside the test hooks, and then the draws are not to be
+// trusted -- the next read of the trace fails loudly instead of delivering them.
+static int check_handoffs(seir_sampler *s) {
+    if (s->pair_debug != 0) return 0;                     // the hooks make roles late on purpose
+    std::vector<uint32_t> late((size_t)s->cfg.B, 0u);
+    HIP_TRY(hipMemcpy(late.data(), s->ch.late, sizeof(uint32_t) * late.size(), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < late.size(); ++b)
+        if (late[b])
+            return fail(SEIR_ERR_STATE, "chain %d: %u in-launch hand-off(s) timed out -- draws since the last check are unreliable "
+                        "(hmc_mode 2 / moves_mode 3 select the multi-launch forms)", (int)b, late[b]);
+    return 0;
+}
+
 static int check_ev_overflow(seir_sampler *s) {
+    int rc = check_handoffs(s);
+    if (rc) return rc;
     if (!s->cfg.ev16) return 0;
     unsigned flag = 0;
     HIP_TRY(hipMemcpy(&flag, s->ch.ev_overflow, sizeof(flag), hipMemcpyDeviceToHost));
