@@ -1231,13 +1231,12 @@ __device__ inline double reduce_chain(const Dims &d, const Consts &c, const Work
 // with_rowconst (fused evaluation): the row constants were written in the previous launch and are summed here
 // (and left in Work::constsum, as k_colreduce does in the other forms)
 template <bool GRAD>
-__global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const double *__restrict__ u_all,
-                                               double *__restrict__ logp, double *__restrict__ grad, int with_rowconst) {
+__device__ __forceinline__ void finish_chain(const Dims &d, const Consts &c, const Work &w, const double *__restrict__ u_all,
+                                             double *__restrict__ logp, double *__restrict__ grad, int with_rowconst, int b) {
     extern __shared__ double lds_col[];             // [Tp]
     __shared__ double sh[4];
     __shared__ double seg[256];
     __shared__ double2 ltab[LDSTAB_N];
-    const int b = d.b0 + blockIdx.x;
     double rcs = 0.0;
     if (with_rowconst)
         for (int m = threadIdx.x; m < d.M; m += 256) rcs += w.rowconst[(size_t)b * d.Mp + m];
@@ -1253,6 +1252,116 @@ __global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const 
         const double *sc = w.scal + (size_t)b * NSCAL;
         logp[b] = lp + (with_rowconst ? rcs : w.constsum[b]) + sc[SC_PRIOR] + sc[SC_JAC];
     }
+}
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const double *__restrict__ u_all,
+                                               double *__restrict__ logp, double *__restrict__ grad, int with_rowconst) {
+    finish_chain<GRAD>(d, c, w, u_all, logp, grad, with_rowconst, d.b0 + blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// k_eval_all: the whole stateless evaluation in ONE launch (8 chains, one XCD each -- the XCD-local hand-off of
+// sampler_kernels.h, k_se_chunk: producers' stores are in the XCD's L2 before they count themselves in, consumers
+// have higher block ids, wait on the chain's counter and read nothing they or a neighbour on their CU could have read
+// before it was written).  Block id mod 8 = chain in every segment (all segment sizes are multiples of 8):
+//   [parameter block | tiles: their share of the state scan, then the contraction with the S->E epilogue |
+//    row-constant blocks | I->R fold | finish]
+//   parameter block, the tiles' state parts -> counter A -> tiles (X, KS, ea, eb), fold (per-block I->R partials)
+//   tiles, row constants, fold -> counter B -> finish
+// Against the three-launch form it saves two launch ramps and boundaries and the idle time between them; same
+// arithmetic, same bits.  cnt: [8][2 TAIL-like lines]: A at cnt[chain * 32], B at cnt[chain * 32 + 16].
+// ---------------------------------------------------------------------------
+constexpr int EVC_STRIDE = 32;          // 64-bit words per chain: counters A and B in lines of their own
+__device__ __forceinline__ void evc_arrive(unsigned long long *p_) {
+    __syncthreads();                                   // vmcnt(0): this block's stores are in the XCD's L2
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(p_, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void evc_wait(const unsigned long long *p_, unsigned long long target, int *err) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { atomicAdd(err, 1); break; }     // ~0.1 s: reported by the host, no hang
+        }
+    }
+    __syncthreads();
+}
+template <bool GRAD, int TN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_eval_all(Dims d, Consts c, Work w, const double *__restrict__ events, const double *__restrict__ u_all,
+                double *__restrict__ logp, double *__restrict__ grad, unsigned long long *cnt,
+                unsigned long long targetA, unsigned long long targetB, int *err, int do_finish) {
+#ifdef EVAL_STAMPS
+#define ESTAMP(i) do { if (threadIdx.x == 0 && chain == 0 && tile_or0 == 0) cnt[8 * EVC_STRIDE + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ESTAMP(i) do {} while (0)
+#endif
+    constexpr int NB = 8;
+    const int per = d.ntc * d.nmt, ncb = d.Tp / WAVE;
+    const int nP = NB, nT = per * NB, nC = d.nrb_scan * NB, nR = ncb * NB;
+    int L = blockIdx.x;
+    const int chain = L & (NB - 1);
+    unsigned long long *cA = cnt + (size_t)chain * EVC_STRIDE, *cB = cA + EVC_STRIDE / 2;
+    if (L < nP) {                                           // the chain's parameter tables
+        __shared__ double sh[4];
+        __shared__ double seg[256];
+        if (threadIdx.x >= 256) return;                     // param_tables is written for 256 threads
+        param_tables(d, c, w, d.b0 + chain, u_all + (size_t)(d.b0 + chain) * d.P, seg, sh);
+        evc_arrive(cA);
+        return;
+    }
+    L -= nP;
+    if (L < nT) {
+        // a tile workgroup first scans its share of the chain's row blocks (the state part: X, KS, I->R partials) -- one
+        // workgroup per CU from the first cycle, and no second tile can land on a CU that already carries one, which
+        // separate state blocks ahead of the tiles made happen (the matrix work of such a CU doubles) -- then waits
+        // for the whole chain's state and evaluates its tile
+        const int tile = L / NB;
+        const int tile_or0 = tile;
+        ESTAMP(0);
+        const int rbt = (d.nrb_scan + per - 1) / per;
+        for (int k = 0; k < rbt; ++k) {
+            const int rb = tile * rbt + k;
+            if (rb < d.nrb_scan) scan_rows<0, 1>(d, c, w, events, rb, chain);
+            __syncthreads();                                // the next row block reuses the scan's LDS
+        }
+        ESTAMP(1);
+        evc_arrive(cA);
+        evc_wait(cA, targetA, err);
+        ESTAMP(2);
+        gemm_se_tile<GRAD, TN>(d, c, w, tile % d.ntc, tile / d.ntc, chain);
+        ESTAMP(3);
+        evc_arrive(cB);
+        return;
+    }
+    L -= nT;
+    if (L < nC) {
+        scan_rows<0, 2>(d, c, w, events, L / NB, chain);
+        evc_arrive(cB);
+        return;
+    }
+    L -= nC;
+    if (L < nR) {
+        evc_wait(cA, targetA, err);
+        if (threadIdx.x >= 256) return;                     // colreduce_block is written for 256 threads
+        colreduce_block(d, w, L / NB, chain, /*with_const=*/false);
+        evc_arrive(cB);
+        return;
+    }
+    if (!do_finish) return;
+    const int tile_or0 = 0;
+    ESTAMP(4);
+    evc_wait(cB, targetB, err);
+    ESTAMP(5);
+    if (threadIdx.x >= 256) return;
+    finish_chain<GRAD>(d, c, w, u_all, logp, grad, 1, d.b0 + chain);
+    ESTAMP(6);
+}
+#undef ESTAMP
+template <int TN>
+inline size_t eval_all_lds_bytes(const Dims &d) {
+    const size_t a = eval_tiles_lds_bytes<TN>(), b2 = (size_t)SCAN_WAVES * d.Tp * 2 * sizeof(double);
+    return a > b2 ? a : b2;
 }
 
 }  // namespace seir

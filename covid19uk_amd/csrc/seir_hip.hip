@@ -54,7 +54,11 @@ struct seir_ctx {
     bool prepared = false;
     int opt_skew = 0, opt_affinity = 3;     // seir_set_option
     int opt_gemm_f32 = 0;
-    int opt_eval_form = 0;            // 0 fused (three launches), 1 four launches
+    int opt_eval_form = 0;            // 0 auto (one launch where a chain's blocks share an XCD, else three), 1 four launches, 2 three
+    int xcd_local = -1;               // -1 not probed yet; 1: blocks with the same id mod 8 share an XCD, eight different ones
+    unsigned long long *eval_cnt = nullptr;   // [8][EVC_STRIDE] k_eval_all's counters
+    int *eval_err = nullptr;          // k_eval_all: waits that timed out
+    unsigned long long eval_a = 0, eval_b = 0;   // what a chain's counters A and B show after the launches so far
     std::vector<float> cstar32_host;        // fp32 copy of the padded Cstar, uploaded when the option is first set
 };
 
@@ -308,7 +312,7 @@ extern "C" int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value) {
             ctx->opt_affinity = value;
             return 0;
         case SEIR_OPT_EVAL_FORM:
-            if (value < 0 || value > 1) return fail(SEIR_ERR_INVALID, "eval form is 0 (fused) or 1 (four launches)");
+            if (value < 0 || value > 2) return fail(SEIR_ERR_INVALID, "eval form is 0 (auto), 1 (four launches) or 2 (three launches)");
             ctx->opt_eval_form = value;
             return 0;
         case SEIR_OPT_GEMM_F32: {
@@ -454,6 +458,64 @@ static Dims fused_dims(const LaunchCfg &l) {
     d.ntc = d.Tp / TN;
     return d;
 }
+// Do blocks with the same id mod 8 share an XCD on this GPU, eight different ones for the eight classes?  (XCC_ID of a
+// probe grid; the XCD-local hand-offs inside a launch -- k_eval_all here, k_se_chunk and the band workgroups of
+// k_move_pair in the sampler -- are used only then.)
+static bool probe_xcd_local(hipStream_t st) {
+    const int nblk = 8 * 144;
+    unsigned *xcc = nullptr;
+    std::vector<unsigned> host(nblk, 99u);
+    hipError_t e = hipMalloc((void **)&xcc, nblk * sizeof(unsigned));
+    if (e != hipSuccess) return false;
+    hipLaunchKernelGGL(k_xcc_probe, dim3(nblk), dim3(256), 0, st, xcc);
+    e = hipMemcpyAsync(host.data(), xcc, nblk * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(xcc);
+    bool ok = e == hipSuccess;
+    for (int L = 8; L < nblk && ok; ++L) ok = host[L] == host[L & 7] && host[L] < 16u;
+    for (int a = 0; a < 8 && ok; ++a)
+        for (int b2 = a + 1; b2 < 8; ++b2) ok = ok && host[a] != host[b2];
+    return ok;
+}
+
+template <int TN>
+static void launch_finish_fused(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, double *logp_dev, double *grad_dev);
+// The whole evaluation in one launch (k_eval_all): 8 chains, XCD-affine block ids, the GPU's XCD placement checked.
+template <int TN>
+static int launch_eval_all(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, const double *events_dev,
+                           double *logp_dev, double *grad_dev) {
+    if (!ctx->eval_cnt) {
+        int rc = dev_alloc(ctx, &ctx->eval_cnt, (size_t)8 * EVC_STRIDE + 16);
+        if (!rc) rc = dev_alloc(ctx, &ctx->eval_err, 1);
+        if (rc) return rc;
+    }
+    Dims d = fused_dims<TN>(l);
+    d.aff_nb = 0;
+    const int per = d.ntc * d.nmt, ncb = d.Tp / WAVE;
+    ctx->eval_a += (unsigned long long)(per + 1);                       // per chain: the tiles' state parts + the parameter block
+    ctx->eval_b += (unsigned long long)(per + d.nrb_scan + ncb);        //            tiles + row-constant blocks + I->R fold blocks
+    const size_t lds = eval_all_lds_bytes<TN>(d);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_eval_all<true, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_eval_all<false, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const dim3 grid((unsigned)((1 + per + d.nrb_scan + ncb + 1) * 8));
+    // the reduction block runs inside the launch for value-only calls; with the gradient it is its own launch (measured:
+    // the gradient assembly takes 12.7 us as the last block of this large kernel against 4.8 us in k_finish -- 59.2 us
+    // per batch against 56.9)
+    const int fin = grad_dev ? 0 : 1;
+    if (grad_dev)
+        hipLaunchKernelGGL((k_eval_all<true, TN>), grid, dim3(512), lds, l.st, d, ctx->c, ctx->w, events_dev, u_dev, logp_dev,
+                           grad_dev, ctx->eval_cnt, ctx->eval_a, ctx->eval_b, ctx->eval_err, fin);
+    else
+        hipLaunchKernelGGL((k_eval_all<false, TN>), grid, dim3(512), lds, l.st, d, ctx->c, ctx->w, events_dev, u_dev, logp_dev,
+                           grad_dev, ctx->eval_cnt, ctx->eval_a, ctx->eval_b, ctx->eval_err, fin);
+    if (!fin) launch_finish_fused<TN>(ctx, l, u_dev, logp_dev, grad_dev);
+    return 0;
+}
+
 template <int TN>
 static void launch_eval_tiles(seir_ctx *ctx, const LaunchCfg &l, const double *events_dev, bool grad) {
     Dims d = fused_dims<TN>(l);
@@ -498,9 +560,21 @@ extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, 
     const LaunchCfg l = whole(ctx, B);
     Dims d = l.d;
     const bool f32 = ctx->opt_gemm_f32 && ctx->c.Cstar32 && ctx->w.Xn32;
-    if (ctx->opt_eval_form == 0 && !f32) {
-        if (d.Tp % 96 == 0) launch_eval_fused<96>(ctx, l, u_dev, events_dev, logp_dev, grad_dev);
-        else launch_eval_fused<64>(ctx, l, u_dev, events_dev, logp_dev, grad_dev);
+    if (ctx->opt_eval_form != 1 && !f32) {
+        bool one = false;
+        if (ctx->opt_eval_form == 0 && B == 8 && (l.affinity & 1)) {
+            if (ctx->xcd_local < 0) ctx->xcd_local = probe_xcd_local(ctx->stream) ? 1 : 0;
+            one = ctx->xcd_local == 1;
+        }
+        if (one) {
+            rc = d.Tp % 96 == 0 ? launch_eval_all<96>(ctx, l, u_dev, events_dev, logp_dev, grad_dev)
+                                : launch_eval_all<64>(ctx, l, u_dev, events_dev, logp_dev, grad_dev);
+            if (rc) return rc;
+        } else if (d.Tp % 96 == 0) {
+            launch_eval_fused<96>(ctx, l, u_dev, events_dev, logp_dev, grad_dev);
+        } else {
+            launch_eval_fused<64>(ctx, l, u_dev, events_dev, logp_dev, grad_dev);
+        }
     } else {
         const size_t lds = ((size_t)SCAN_WAVES * d.Tp * 2 + SCAN_LFT) * sizeof(double);
         if (lds > 64 * 1024)
@@ -522,6 +596,7 @@ extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, 
     return 0;
 }
 
+static int check_eval_handoffs(seir_ctx *ctx);
 static int host_eval(seir_ctx *ctx, int B, const double *u, const double *events, double *logp, double *grad) {
     int rc = check_batch(ctx, B);
     if (rc) return rc;
@@ -536,7 +611,7 @@ static int host_eval(seir_ctx *ctx, int B, const double *u, const double *events
     if (grad)
         HIP_TRY(hipMemcpyAsync(grad, ctx->grad_stage, sizeof(double) * B * d.P, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return check_eval_handoffs(ctx);
 }
 
 extern "C" int seir_log_prob(seir_ctx *ctx, int32_t B, const double *u, const double *events, double *logp) {
@@ -549,9 +624,30 @@ extern "C" int seir_log_prob_grad(seir_ctx *ctx, int32_t B, const double *u, con
     return host_eval(ctx, B, u, events, logp, grad);
 }
 
+#ifdef EVAL_STAMPS
+extern "C" int seir_debug_eval_stamps(seir_ctx *ctx, unsigned long long *out) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, ctx->eval_cnt + 8 * EVC_STRIDE, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+// k_eval_all's bounded waits: a time-out means a consumer block went on without its producers' data
+static int check_eval_handoffs(seir_ctx *ctx) {
+    if (!ctx->eval_err) return 0;
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, ctx->eval_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (n) {
+        (void)hipMemset(ctx->eval_err, 0, sizeof(int));
+        return fail(SEIR_ERR_STATE, "%d in-launch hand-off(s) of the one-launch evaluation timed out: results since the last "
+                    "synchronisation are unreliable (SEIR_OPT_EVAL_FORM 2 selects the three-launch form)", n);
+    }
+    return 0;
+}
+
 extern "C" int seir_sync(seir_ctx *ctx) {
     if (!ctx) return fail(SEIR_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = check_eval_handoffs(ctx)) return rc;
     return 0;
 }
 
@@ -1004,22 +1100,9 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         if (e != hipSuccess) rc = fail(SEIR_ERR_DEVICE, "sampler stream setup failed: %s", hipGetErrorString(e));
     }
     if (!rc && (s->hmc_tail || s->moves_mode == 0 || s->moves_mode == 2)) {
-        // Do blocks with the same id mod 8 share an XCD here?  k_se_chunk hands data between the workgroups of a chain
-        // through that XCD's L2 alone; it is used only if every workgroup of a grid shaped like its own says so.
-        const int nblk = 8 * 144;
-        unsigned *xcc = nullptr;
-        std::vector<unsigned> host(nblk, 99u);
-        hipError_t e = hipMalloc((void **)&xcc, nblk * sizeof(unsigned));
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_xcc_probe, dim3(nblk), dim3(256), 0, ctx->stream, xcc);
-            e = hipMemcpyAsync(host.data(), xcc, nblk * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            (void)hipFree(xcc);
-        }
-        bool ok = e == hipSuccess;
-        for (int L = 8; L < nblk && ok; ++L) ok = host[L] == host[L & 7] && host[L] < 16u;
-        for (int a = 0; a < 8 && ok; ++a)
-            for (int b2 = a + 1; b2 < 8; ++b2) ok = ok && host[a] != host[b2];      // eight different XCDs
+        // Do blocks with the same id mod 8 share an XCD here?  (probe_xcd_local)
+        if (ctx->xcd_local < 0) ctx->xcd_local = probe_xcd_local(ctx->stream) ? 1 : 0;
+        const bool ok = ctx->xcd_local == 1;
         s->xcd_local = ok;
     }
     if (rc) { seir_sampler_destroy(s); return rc; }

@@ -141,7 +141,7 @@ def test_negative_rate_semantics(Model):
         assert np.isnan(model.log_prob(u, ev))
 
 
-@pytest.mark.parametrize("form", ["fused", "four-launch"])
+@pytest.mark.parametrize("form", ["fused", "three-launch", "four-launch"])
 def test_uk380_batch_matches_c_oracle(Model, form):
     case = H.build_case("uk380", 10, alpha_t_sd=0.005)
     u, ev = _batch(case, 8, 10)
@@ -318,3 +318,26 @@ def test_fp32_contraction_needs_128_tiles(Model):
             model.set_option(gemm_f32=True)          # ceil64(11) = 64 is not a multiple of 128
         lp = model.log_prob(case["u"], case["events"])
         assert abs(lp - so.joint_log_prob(case["u"], case["events"], case["k"], "stable")) <= RTOL_LOGP * abs(lp)
+
+
+@pytest.mark.parametrize("name,seed", [("ni11", 23), ("uk380", 24)])
+def test_one_launch_and_three_launch_evaluations_give_the_same_bits(Model, name, seed):
+    """With 8 chains the default form runs state scan, contraction tiles and reduction as ONE launch (k_eval_all:
+    counters in the chain's own L2 line, consumers behind producers in block order) where the GPU places block ids
+    congruent mod 8 on one XCD each; "three-launch" forces the separate launches.  Same code, same order: same bits,
+    call after call (the counters run on), with workgroup skew, and for value-only calls."""
+    case = H.build_case(name, seed, alpha_t_sd=0.005)
+    u, ev = _batch(case, 8, seed)
+    res = {}
+    for form, skew in (("three-launch", 0), ("fused", 0), ("fused", 2)):
+        with Model(case["cov"], case["init"], max_chains=8) as model:
+            model.set_option(eval_form=form, debug_skew=skew)
+            out = []
+            for rep in range(3):
+                lp, g = model.log_prob_grad(u, ev)
+                out.append((lp.copy(), g.copy(), model.log_prob(u, ev).copy()))
+            res[(form, skew)] = out
+    ref = res[("three-launch", 0)]
+    for key in (("fused", 0), ("fused", 2)):
+        for (a, b, c), (x, y, z) in zip(ref, res[key]):
+            assert np.array_equal(a, x) and np.array_equal(b, y) and np.array_equal(c, z), key

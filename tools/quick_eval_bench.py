@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--workload", default="uk380")
     ap.add_argument("--chains", type=int, default=8)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--form", default="fused", choices=["fused", "four-launch"])
+    ap.add_argument("--form", default="fused", choices=["fused", "three-launch", "four-launch"])
     args = ap.parse_args()
     import torch
     import __graft_entry__ as entry
