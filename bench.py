@@ -314,8 +314,10 @@ def main():
     t_hbm = alg_bytes / (HBM_PEAK_GBPS * 1e9)
     t_mfma = 2.0 * M * M * T * B / (F64_MFMA_PEAK_TFLOPS * 1e12)
     t_eval = B / evals["value_and_grad"]
-    stateless = {"path": "seir_log_prob_dev, value + gradient: k_state_params [state scan | parameter tables], "
-                         "k_eval_tiles [fp64 MFMA contraction with the S->E term as epilogue | row constants | I->R fold], k_finish",
+    stateless = {"path": "seir_log_prob_dev, value + gradient, 8 chains: k_eval_all [parameter tables | tiles: their share of the state "
+                         "scan, then the fp64 MFMA contraction with the S->E term as epilogue | row constants | I->R fold] with XCD-local "
+                         "hand-offs inside the launch, then k_finish (inside the same launch for value-only calls); other batch "
+                         "sizes: k_state_params, k_eval_tiles, k_finish",
                  "bound": "mfma" if t_mfma > t_hbm else "hbm",
                  "t_hbm_us": 1e6 * t_hbm, "t_mfma_us": 1e6 * t_mfma, "measured_us_per_batch": 1e6 * t_eval,
                  "frac": max(t_hbm, t_mfma) / t_eval,
@@ -325,7 +327,7 @@ def main():
                  "peak": F64_MFMA_PEAK_TFLOPS if t_mfma > t_hbm else HBM_PEAK_GBPS,
                  "unit": "TFLOP/s" if t_mfma > t_hbm else "GB/s"}
     try:
-        stateless["kernels_us"] = {n: 1e3 * model.time_kernel(n, B, 50) for n in ("state", "tiles_grad", "finish_fused")}
+        stateless["three_launch_form_kernels_us"] = {n: 1e3 * model.time_kernel(n, B, 50) for n in ("state", "tiles_grad", "finish_fused")}
         stateless["four_launch_form_kernels_us"] = {n: 1e3 * model.time_kernel(n, B, 50) for n in ("scan", "gemm", "se_grad", "finish")}
     except Exception as e:                                  # timing hook only
         stateless["kernels_us"] = str(e)
