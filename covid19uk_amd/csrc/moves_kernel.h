@@ -1037,7 +1037,11 @@ __device__ __forceinline__ void mv_rows_to_lds(const Dims &d, const Work &w, con
 
 // state update of an accepted proposal by the calling block (rows, events, row totals, I->R
 // exposure); ends with the stores drained
-__device__ __forceinline__ void mv_apply_rows(const Dims &d, const Work &w, const SamplerCfg &s, int b, const Move &mv) {
+// trans (optional, LDS, thread 0 writes): bit 0 set if a row total of the plane went from zero to non-zero or back,
+// bit 1 the same for a total inside the occult range -- what decides whether a proposal pre-drawn from the old totals
+// would still pick the same rows
+__device__ __forceinline__ void mv_apply_rows(const Dims &d, const Work &w, const SamplerCfg &s, int b, const Move &mv,
+                                              int *trans = nullptr) {
     const int tid = threadIdx.x;
     for (int i = 0; i < mv.n; ++i) {
         const size_t rowoff = ((size_t)b * d.Mp + mv.m[i]) * d.Tp;
@@ -1050,10 +1054,23 @@ __device__ __forceinline__ void mv_apply_rows(const Dims &d, const Work &w, cons
         if (tid == 0) {
             w.K[mv.tgt][rowoff + mv.a[i]] += mv.dka[i];
             if (mv.b[i] >= 0) w.K[mv.tgt][rowoff + mv.b[i]] += mv.dkb[i];
-            w.rowtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += mv.dka[i] + mv.dkb[i];
+            int *prt = w.rowtot + ((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i];
+            const int dk = mv.dka[i] + mv.dkb[i];
             const int ra = (mv.a[i] >= s.tr_lo && mv.a[i] < s.tr_hi) ? mv.dka[i] : 0;
             const int rb = (mv.b[i] >= s.tr_lo && mv.b[i] < s.tr_hi) ? mv.dkb[i] : 0;
-            if (ra + rb != 0) w.rngtot[((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i]] += ra + rb;
+            int *prg = w.rngtot + ((size_t)b * 2 + mv.tgt) * d.Mp + mv.m[i];
+            if (trans != nullptr) {
+                const int rt0 = *prt, rg0 = (ra + rb != 0) ? *prg : 1;
+                int tb = 0;
+                if ((rt0 > 0) != (rt0 + dk > 0)) tb |= 1;
+                if (ra + rb != 0 && (rg0 > 0) != (rg0 + ra + rb > 0)) tb |= 2;
+                *trans |= tb;
+                *prt = rt0 + dk;
+                if (ra + rb != 0) *prg = rg0 + ra + rb;
+            } else {
+                *prt += dk;
+                if (ra + rb != 0) *prg += ra + rb;
+            }
         }
         __syncthreads();     // two updates may touch the same cells
     }
@@ -1314,7 +1331,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     __shared__ PairNote note;
     __shared__ double pre_down[2], s_down[4];
     __shared__ double2 ltab[LDSTAB_N];
-    __shared__ int s_sel, s_acc_se, s_conf, s_late, s_late2, s_use_pre;
+    __shared__ int s_sel, s_acc_se, s_conf, s_late, s_late2, s_use_pre, s_trans;
     debug_skew(d);
     // block id = slot * nbk + chain with the speculative roles in the low slots: they are dispatched first,
     // so an authoritative workgroup never holds a CU waiting for a partner that has not been placed yet,
@@ -1568,7 +1585,8 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         lds_barrier();
         se_acc = s_acc_se != 0;
         if (se_acc && !waited) { wait_roles(); waited = true; }
-        if (se_acc) mv_apply_rows(d, w, s, b, mv);
+        if (tid == 0) s_trans = 0;
+        if (se_acc) mv_apply_rows(d, w, s, b, mv, &s_trans);       // (its first barrier orders the store above)
         if (tid == 0) {
             if (se_acc) {
                 double *hs = ch.hs + (size_t)b * NHS;
@@ -1622,12 +1640,24 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     if (do_pre && tid == 0) {
         // (field by field: a struct assembled in a local and assigned is copied through scratch memory)
         int *nt = reinterpret_cast<int *>(ch.prev + (size_t)(pbuf ^ 1) * s.B + b);
-        // if the wait never happened nothing was written in this launch, and a late role 2 read the final state
-        nt[0] = (!se_acc && !(waited && late2)) ? 1 : 0;                       // PairNote::ok
-        const int nrows = pend_acc ? pendp->n : 0;
-        nt[1] = nrows;                                                          // PairNote::n
+        // if the wait never happened nothing was written in this launch, and a late role 2 read the final state.
+        // An S->E-type update accepted in this launch does not by itself rule the pre-drawn proposal out: it was drawn
+        // from the totals at entry, and what a proposal takes from the totals is WHICH rows hold events (and the
+        // total of the row it picks) -- unless one of the updated rows went from none to some or back in the totals
+        // the pre-drawn kind reads (row totals for an event-time move, occult-range totals for an occult), it picks
+        // the same rows, and unless it picked an updated row (checked by the next launch against the rows noted
+        // here, like the rows of an accepted E->I-type update) it finds them as it saw them.
+        const int n_pend = pend_acc ? pendp->n : 0, n_se = se_acc ? sm_se.mv.n : 0;
+        const bool se_keeps = !se_acc || (((s_trans & (se_next.kind == 0 ? 1 : 2)) == 0) && n_pend + n_se <= MMAX);
+        nt[0] = (se_keeps && !(waited && late2)) ? 1 : 0;                       // PairNote::ok
+        nt[1] = n_pend + (se_keeps ? n_se : 0);                                 // PairNote::n
 #pragma unroll
-        for (int j = 0; j < MMAX; ++j) nt[2 + j] = j < nrows ? pendp->m[j] : -1;   // PairNote::rows
+        for (int j = 0; j < MMAX; ++j) {
+            int row = -1;
+            if (j < n_pend) row = pendp->m[j];
+            else if (se_keeps && j - n_pend < n_se) row = sm_se.mv.m[j - n_pend];
+            nt[2 + j] = row;                                                    // PairNote::rows
+        }
     }
     if (nband > 0) {                                       // band workgroups may go: descriptors, mvsel and fpend are in L2
         __syncthreads();
