@@ -1124,9 +1124,11 @@ static_assert(sizeof(PairNote) == (2 + MMAX) * sizeof(int), "k_move_pair writes 
 //   role 2: draws the S->E-type proposal `se_next` of the NEXT launch from the state at entry, and its
 //     log-ratio over the rows it updates (Chains::mvs / Chains::DownS[pbuf^1]).  An S->E-type proposal reads
 //     only its own rows and the S->E plane's row (or occult-range) totals, so it is still the proposal the
-//     next launch would draw unless (a) this launch's own S->E-type update is accepted (the totals of the
-//     plane may move), (b) one of its rows is a row of an E->I-type update accepted in between (the pending
-//     one of this launch or the one finalized at the start of the next), or (c) this workgroup was late.
+//     next launch would draw unless (a) this launch's own S->E-type update is accepted AND turns a row total of
+//     the kind the proposal reads on or off (which rows hold events is all a proposal takes from the totals,
+//     besides the total of the row it picks), (b) one of its rows is a row of an update accepted in between
+//     (this launch's S->E-type one, the pending E->I-type one of this launch or the one finalized at the start
+//     of the next), or (c) this workgroup was late.
 //     (a)-(c) are all decided by role 0 without looking at role 2's output; the next launch then draws the
 //     update itself, exactly as before.  If the E->I-type update finalized at the start of the next launch
 //     is accepted, F moved under the proposal's rows and only the log-ratio is recomputed.
