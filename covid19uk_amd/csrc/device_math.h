@@ -159,9 +159,18 @@ __device__ __forceinline__ double log1mexp(double r) { return log(-expm1(-r)); }
 // Out-of-line libm for the once-per-launch scalar work: inlining every exp/log/log1p copy makes
 // the single-workgroup kernels several thousand instructions of straight-line code that is
 // fetched cold on every launch.
-__device__ __attribute__((noinline)) double cold_exp(double x) { return exp(x); }
-__device__ __attribute__((noinline)) double cold_log(double x) { return log(x); }
-__device__ __attribute__((noinline)) double softplus(double x) {
+// The once-per-launch scalar paths (softplus of two parameters, the accept test's log, the Box-Muller normals) used to
+// be real calls, to keep the single-pass kernels' images small.  A kernel that contains a call needs a private segment,
+// and the dispatcher places the waves of such a kernel more slowly: k_se_chunk's 384 workgroups and the stage kernels
+// lost ~12 us per sweep to it (r02).  SEIR_COLD_CALLS restores the calls for comparison.
+#ifdef SEIR_COLD_CALLS
+#define SEIR_COLD __attribute__((noinline))
+#else
+#define SEIR_COLD __forceinline__
+#endif
+__device__ SEIR_COLD double cold_exp(double x) { return exp(x); }
+__device__ SEIR_COLD double cold_log(double x) { return log(x); }
+__device__ SEIR_COLD double softplus(double x) {
     return x > 0.0 ? x + log1p(cold_exp(-x)) : log1p(cold_exp(x));
 }
 

@@ -176,7 +176,7 @@ constexpr int NRED = 8;
 #endif
 
 // standard normal for component i of the momentum (Box-Muller; components 2j, 2j+1 share a Philox call)
-__device__ __attribute__((noinline)) double momentum_normal(RngKey key, int i) {
+__device__ SEIR_COLD double momentum_normal(RngKey key, int i) {
     double u1, u2;
     rng_uniform2(key, RS_MOMENTUM, (uint32_t)(i >> 1), u1, u2);
     const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
