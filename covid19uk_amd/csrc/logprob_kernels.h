@@ -647,6 +647,11 @@ __device__ __forceinline__ void se_tile(const Dims &d, const Consts &c, const Wo
     const int b = d.b0 + bz, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = bx * WAVE + lane;
     const int m0 = by * SE_TM + wave * SE_RW;
+#ifdef SE_STAMPS
+    // developer timeline (tools/dev/se_timeline.py): start / end of every tile workgroup in the two free tile scalars
+    unsigned long long se_t0 = 0;
+    if (GRAD && SRC == 1 && TSM == 1) se_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x < LOGTAB_N) ltab[threadIdx.x] = c.logtab[threadIdx.x];   // barrier below, after the loads
     const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
     const double ea_t = w.ea[(size_t)b * d.Tp + t];
@@ -750,6 +755,20 @@ __device__ __forceinline__ void se_tile(const Dims &d, const Consts &c, const Wo
             if (lane == 0) { w.TS[tile * 4 + 2] = rl; w.TS[tile * 4 + 3] = rs; }
         }
     }
+#ifdef SE_STAMPS
+    if (GRAD && SRC == 1 && TSM == 1) {
+        __syncthreads();                                  // every wave's stores issued and acknowledged
+        if (threadIdx.x == 0) {
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned long long *ts = reinterpret_cast<unsigned long long *>(w.TS);
+            ts[tile * 4 + 2] = se_t0;
+            ts[tile * 4 + 3] = (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffull) | ((unsigned long long)(xcc & 0xf) << 60) |
+                               ((unsigned long long)((hw >> 8) & 0xfff) << 48);
+        }
+    }
+#endif
 }
 
 template <bool GRAD, int SRC, int TSM = 0>

@@ -1642,6 +1642,14 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
     return 0;
 }
 
+#ifdef SE_STAMPS
+extern "C" int seir_debug_read_ts(seir_ctx *ctx, double *out, int64_t n) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, ctx->w.TS, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 extern "C" int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out) {
     int rc = sampler_check(s);
     if (rc) return rc;
