@@ -838,7 +838,10 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             for (int j0 = 0; j0 < nmt; j0 += 12) {
                 double x[12];
 #pragma unroll
-                for (int j = 0; j < 12; ++j) x[j] = j0 + j < nmt ? LDP(kp + (size_t)(j0 + j) * d.Tp) : 0.0;
+                for (int j = 0; j < 12; ++j) {             // clamped index + select: a conditional L1-bypassing load is a branch
+                    const double v_ = LDP(kp + (size_t)min(j0 + j, nmt - 1) * d.Tp);
+                    x[j] = j0 + j < nmt ? v_ : 0.0;
+                }
 #pragma unroll
                 for (int j = 0; j < 12; j += 4) { c0 += x[j]; c1 += x[j + 1]; c2 += x[j + 2]; c3 += x[j + 3]; }
             }
@@ -849,13 +852,23 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) {
             const bool on = cc < ntc && lane < nmt;
-            bs[cc] = on ? LDP(TS + ((size_t)lane * ntc + cc) * 4) : 0.0;
-            as[cc] = on ? LDP(TS + ((size_t)lane * ntc + cc) * 4 + 1) : 0.0;
+            const double *tp_ = TS + ((size_t)min(lane, nmt - 1) * ntc + min(cc, ntc - 1)) * 4;
+            const double b_ = LDP(tp_), a_ = LDP(tp_ + 1);
+            bs[cc] = on ? b_ : 0.0;
+            as[cc] = on ? a_ : 0.0;
         }
-        for (int r = lane + WAVE; r < nmt; r += WAVE)
+        // more than 64 row tiles (M > 1024): three chunks' scalars in flight at a time -- all of them at once were the
+        // register peak of the whole role (24 more VGPRs), paid by every problem size
+        for (int r = lane + WAVE; r < nmt; r += WAVE) {
 #pragma unroll
-            for (int cc = 0; cc < NC; ++cc)
-                if (cc < ntc) { bs[cc] += LDP(TS + ((size_t)r * ntc + cc) * 4); as[cc] += LDP(TS + ((size_t)r * ntc + cc) * 4 + 1); }
+            for (int c0 = 0; c0 < NC; c0 += 3) {
+#pragma unroll
+                for (int cc = c0; cc < c0 + 3 && cc < NC; ++cc)
+                    if (cc < ntc) { bs[cc] += LDP(TS + ((size_t)r * ntc + cc) * 4); as[cc] += LDP(TS + ((size_t)r * ntc + cc) * 4 + 1); }
+#pragma unroll
+                for (int cc = c0; cc < c0 + 3 && cc < NC; ++cc) asm volatile("" : "+v"(bs[cc]), "+v"(as[cc]));   // the sums, here
+            }
+        }
         lds_barrier();                                     // ltab (single wave: orders the LDS writes)
         const double gg0 = wave_sum(cg0_l), gg1 = wave_sum(cg1_l);
         // Everything that couples the chunks is linear in the tile scalars, so each lane forms its
@@ -944,14 +957,6 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         }
         const bool rows_here = d.chunked == 1;             // small M: sum_m l_m R_m, sum_m s_m R_m from the row partials
         constexpr int RPL = 8;                             // Mp <= 512: rows lane, lane+64, ...
-        double la_[RPL], sp_[RPL];
-#pragma unroll
-        for (int k = 0; k < RPL; ++k) {
-            const int mm = lane + k * WAVE;
-            const bool on = rows_here && mm < M;
-            la_[k] = on ? c.la[mm] : 0.0;
-            sp_[k] = on ? spr[mm] : 0.0;
-        }
         wait();
         // ---- from here on: this step's partial sums
         double R = 0.0;
@@ -978,25 +983,35 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             for (int j = 0; j < 4; ++j) { ps += x[j]; rl += y[j]; rs += z[j]; }
         }
         if (rows_here) {
-            // ntc partials per row, one batch of loads
-            double Rr[RPL];
-#pragma unroll 4
-            for (int k = 0; k < RPL; ++k) {
-                const int mm = lane + k * WAVE;
-                const bool on = mm < M;
-                double acc = 0.0;
-                if (on) {
-                    const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + mm;
-                    double x[NC];
+            // ntc partials per row, and the row's l_m and s_m with them: the same round trip, and nothing held in
+            // registers across the wait (sixteen values per lane were: with them this role needed 113 VGPRs, and the
+            // gradient launch that carries it, k_se_chunk, stays at five waves per SIMD only up to 96)
+            const int nrow = (M + WAVE - 1) / WAVE;          // uniform
+            for (int k0 = 0; k0 < RPL; k0 += 3) {
+                if (k0 >= nrow) break;
+                double lx[3], sx[3], x[3][NC];
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) x[j] = j < ntc ? LDP(rp + (size_t)j * d.Mp) : 0.0;
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int mm = lane + (k0 + kk) * WAVE;
+                    const bool on = k0 + kk < RPL && mm < M;
+                    const int mc = on ? mm : 0;
+                    const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + mc;
+                    lx[kk] = on ? c.la[mc] : 0.0;
+                    sx[kk] = on ? spr[mc] : 0.0;
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) acc += x[j];
+                    for (int j = 0; j < NC; ++j) {
+                        const double v_ = LDP(rp + (size_t)(j < ntc ? j : 0) * d.Mp);
+                        x[kk][j] = (on && j < ntc) ? v_ : 0.0;
+                    }
                 }
-                Rr[k] = acc;
-            }
 #pragma unroll
-            for (int k = 0; k < RPL; ++k) { rl = fma(la_[k], Rr[k], rl); rs = fma(sp_[k], Rr[k], rs); }
+                for (int kk = 0; kk < 3; ++kk) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) acc += x[kk][j];
+                    rl = fma(lx[kk], acc, rl); rs = fma(sx[kk], acc, rs);
+                }
+            }
         }
         ps = wave_sum(ps); rl = wave_sum(rl); rs = wave_sum(rs);
         const double g = own ? sig * R - Qs : 0.0;
@@ -1051,29 +1066,46 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
 // itself in, and the roles read the partial sums past their L1.  The roles write the NEXT position's tables (ea,
 // eb, psi ...) only after every tile of the chain has counted in, i.e. has long read the current ones.  Results are
 // bit-identical to k_se followed by k_hmc_chunk.
+constexpr int TAIL_BACKOFF = 60;     // x 64 cycles
 template <int TSM, int NTC>
-#ifdef TAIL_X_OCC5
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
-#else
 __global__ __launch_bounds__(256)
-#endif
 void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsigned long long target) {
     const int ntile = d.ntc * d.nmt, n_tiles = ntile * d.aff_nb;
     if ((int)blockIdx.x < n_tiles) {
         int bz, tile;
         xcd_affine(blockIdx.x, ntile, d.aff_nb, bz, tile);
+#ifdef TAIL_STAMPS
+        // developer timeline (tools/dev/tail_timeline.py), in the unused words of the chain's counter line of ANOTHER
+        // buffer slot (words 8..15 of the line: the counter itself is word 0): 8 first tile start, 9 last tile arrival,
+        // 10 first role past its wait, 11 last role past its wait, 12 last role done, 13 first role start -- of the launches
+        // with par = 1 since the last reset (the probe runs trajectories of three leapfrog steps: exactly one such launch)
+        unsigned long long *stp = ch.tail + (size_t)(d.b0 + bz) * TAIL_STRIDE + 8;
+        if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_min(stp + 0, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         se_tile<true, 1, TSM>(d, c, w, tile % d.ntc, tile / d.ntc, bz);
         __syncthreads();                               // vmcnt(0): this tile's partial sums are in the XCD's L2
         if (threadIdx.x == 0)
             __hip_atomic_fetch_add(ch.tail + (size_t)(d.b0 + bz) * TAIL_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TAIL_STAMPS
+        if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_max(stp + 1, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         return;
     }
     if (threadIdx.x >= WAVE) return;                   // a role is one wave
     const int L = (int)blockIdx.x - n_tiles;
     const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
     const unsigned long long *cnt = ch.tail + (size_t)b * TAIL_STRIDE;
+#ifdef TAIL_STAMPS
+    unsigned long long *stp = ch.tail + (size_t)b * TAIL_STRIDE + 8;
+    if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_min(stp + 5, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     hmc_chunk_role<NTC, true>(d, c, w, s, ch, par, role, b, [&] {
         int spins = 0;
+        // back off before the first look at the counter: since the roles fit beside all the tiles (96 VGPRs, five waves
+        // per SIMD) they are resident from the start of the launch, and 96 waves polling the lines the tiles count
+        // themselves in on made the whole launch slower than at four waves per SIMD (12.7 us against 12.1); with the
+        // first ~1.8 us slept through -- no tile phase of this size is shorter -- it is the faster form (11.8)
+        if (ntile >= 32) __builtin_amdgcn_s_sleep(TAIL_BACKOFF);
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 22)) {                 // ~0.1 s: never seen; counted like k_move_pair's time-outs, no hang
@@ -1081,7 +1113,18 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
                 break;
             }
         }
+#ifdef TAIL_STAMPS
+        if (threadIdx.x == 0 && par == 1) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            __hip_atomic_fetch_min(stp + 2, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(stp + 3, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
     });
+#ifdef TAIL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_max(stp + 4, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 // XCC_ID of every workgroup of a grid laid out like the XCD-affine grids: the host checks that blocks with the same

@@ -1650,6 +1650,26 @@ extern "C" int seir_debug_read_ts(seir_ctx *ctx, double *out, int64_t n) {
 }
 #endif
 
+#ifdef TAIL_STAMPS
+// words 8..15 of every chain's counter line; reset = 1: min-words to ~0, max-words to 0 (call before the launch to look at)
+extern "C" int seir_debug_tail_stamps(seir_sampler *s, unsigned long long *out, int reset) {
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    const int B = s->cfg.B;
+    std::vector<unsigned long long> h((size_t)B * TAIL_STRIDE);
+    HIP_TRY(hipMemcpy(h.data(), s->ch.tail, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < 8; ++k) out[b * 8 + k] = h[(size_t)b * TAIL_STRIDE + 8 + k];
+    if (reset) {
+        for (int b = 0; b < B; ++b) {
+            unsigned long long *p = h.data() + (size_t)b * TAIL_STRIDE + 8;
+            p[0] = p[2] = p[5] = ~0ull; p[1] = p[3] = p[4] = 0;
+        }
+        HIP_TRY(hipMemcpy(s->ch.tail, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+#endif
+
 extern "C" int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out) {
     int rc = sampler_check(s);
     if (rc) return rc;
