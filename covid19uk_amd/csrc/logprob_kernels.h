@@ -619,19 +619,23 @@ constexpr int SE_RS = 72;       // LDS row stride (doubles) of the row-sum trans
 // id = chain): partial sums, proposal descriptors and the planes a chain's kernels hand to each
 // other are then found in that XCD's L2 instead of at the cross-XCD rate.
 // Maps the linear block id L of a 1-D grid of per*nb blocks to (chain, tile); the host only sets
-// aff_nb when nb is 1, 2, 4 or 8 and per*nb is a multiple of 8 (otherwise the natural 2-D grid).
+// aff_nb when nb is 1, 2, 4 or a multiple of 8 (then several chains share an XCD, each still whole on one) and
+// per*nb is a multiple of 8 (otherwise the natural 2-D grid).
 __device__ __forceinline__ void xcd_affine(int L, int per, int nb, int &chain, int &tile) {
     const int l = L & 7;
     if (nb == 8) {
         chain = l;
         tile = L >> 3;
+    } else if (nb > 8) {                 // a multiple of 8: chain mod 8 = block id mod 8
+        chain = L % nb;
+        tile = L / nb;
     } else {
         chain = l % nb;
         tile = (L >> 3) * (8 / nb) + l / nb;
     }
 }
 inline bool xcd_affinity_applies(int per, int nb) {
-    return (nb == 1 || nb == 2 || nb == 4 || nb == 8) && ((long long)per * nb) % 8 == 0;
+    return (nb == 1 || nb == 2 || nb == 4 || (nb > 0 && nb % 8 == 0)) && ((long long)per * nb) % 8 == 0;
 }
 
 // TSM (sampler, GRAD, SRC 1): tile scalars for the chunked leapfrog -- 0 none, 1 column scalars,

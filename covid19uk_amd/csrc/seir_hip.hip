@@ -1360,7 +1360,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         // chunk roles inside the gradient launch (k_se_chunk): 8 chains, one XCD each (checked at creation), the
         // XCD-affine grid, no graph capture in progress (the ticket counter does not care, but keep the two apart)
         const int ntile_se = d0.ntc * d0.nmt;
-        const bool tail = s->hmc_tail && s->xcd_local && nb == 8 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nb) &&
+        const bool tail = s->hmc_tail && s->xcd_local && nb % 8 == 0 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nb) &&
                           !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && ts_mode != 0;
         for (int i = 1; i < c.L; ++i) {
             l.d.sp_par = par;
@@ -1426,7 +1426,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             int cus = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
             const int nband_fit = (d.M + 15) / 16;                      // 16 rows per band workgroup: two per wave
-            const bool band_in_pair = s->moves_mode != 3 && s->xcd_local && nb == 8 && s->ngroups == 1 && !s->use_graph &&
+            const bool band_in_pair = s->moves_mode != 3 && s->xcd_local && nb % 8 == 0 && s->ngroups == 1 && !s->use_graph &&
                                       (3 + nband_fit) * nb <= cus;
             const int nband = band_in_pair ? nband_fit : 0;
             SamplerCfg cp = c;

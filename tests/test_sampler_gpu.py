@@ -508,13 +508,13 @@ def test_compact_event_trace_is_lossless_and_guards_its_range(api):
 
 
 @pytest.mark.gpu
-def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api):
-    """hmc="chunk" with 8 chains runs the chunk roles of a leapfrog step inside the gradient launch (k_se_chunk: the
+@pytest.mark.parametrize("B", [8, 16])
+def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
+    """hmc="chunk" with a multiple of 8 chains (chain b on XCD b mod 8) runs the chunk roles of a leapfrog step inside the gradient launch (k_se_chunk: the
     last workgroups of a chain to arrive take the roles; hand-off through the XCD's L2) when the GPU places block ids
     congruent mod 8 on one XCD each; hmc="chunk-split" launches them separately.  Same arithmetic in the same order:
     every traced quantity must agree to the last bit, with and without workgroup skew."""
     case = H.build_case("ni11", 31)
-    B = 8
     u = synth.jitter_params(case["u"], B, scale=0.01, seed=3, T=case["k"].T)
     ev = np.stack([case["events"]] * B)
     cfg = dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=2)
@@ -542,10 +542,11 @@ def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,cfg,eps", [("ni11", dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
-                                          ("uk380", dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5)])
-def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, cfg, eps):
-    """moves="paired" with 8 chains evaluates the band part of the E->I-type log-ratio with more workgroups of the
+@pytest.mark.parametrize("name,B,cfg,eps", [("ni11", 8, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
+                                            ("ni11", 16, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
+                                            ("uk380", 8, dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5)])
+def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, B, cfg, eps):
+    """moves="paired" with a multiple of 8 chains whose workgroups all fit the chip at once evaluates the band part of the E->I-type log-ratio with more workgroups of the
     k_move_pair launch (pair_band_block: done-tokens and an XCD-local hand-off, the F band of the update accepted in
     the launch added on the fly and applied once every role is done) where the GPU places block ids congruent mod 8
     on one XCD each; moves="paired-delta" always launches k_move_delta for it.  The two sum the band's cells in a
@@ -553,7 +554,6 @@ def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, cf
     continuous quantities agree to 1e-12 -- with and without workgroup skew and with the speculative roles made late
     (among themselves the in-pair runs must agree to the last bit)."""
     case = H.build_case(name, 41)
-    B = 8
     n = 30 if name == "ni11" else 12
     u = synth.jitter_params(case["u"], B, scale=0.01 if name == "ni11" else 0.002, seed=5, T=case["k"].T)
     ev = np.stack([case["events"]] * B)
