@@ -1053,8 +1053,8 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
 // k_se_chunk: the gradient tiles of a leapfrog step AND the chunk roles of that step in one launch -- what it saves is
 // the chunk kernel's launch ramp and boundary (~2.5 us, fifteen times per sweep) and, because a role issues every
 // load that does not depend on the tiles while they are still running, most of its memory latency as well.
-// Grid: the XCD-affine tile grid of k_se (ntile x 8 blocks) followed by (ntc + Mp/64) x 8 role blocks (block id mod 8 =
-// chain there too).  A tile workgroup evaluates its tile exactly as k_se does and then counts itself in on the chain's
+// Grid: the XCD-affine tile grid of k_se (ntile x nb blocks, nb a multiple of 8) followed by (ntc + Mp/64) x nb role
+// blocks (block id mod 8 = chain mod 8 there too).  A tile workgroup evaluates its tile exactly as k_se does and then counts itself in on the chain's
 // counter (Chains::tail, one cache line per chain); a role workgroup (one wave) issues its independent loads, waits
 // until the counter shows `target` -- every tile of the chain, of every launch so far -- and runs the role.  Blocks
 // are dispatched in id order, so a role is placed only after every tile has been: it can never hold a slot that an
@@ -1075,8 +1075,9 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
         int bz, tile;
         xcd_affine(blockIdx.x, ntile, d.aff_nb, bz, tile);
 #ifdef TAIL_STAMPS
-        // developer timeline (tools/dev/tail_timeline.py), in the unused words of the chain's counter line of ANOTHER
-        // buffer slot (words 8..15 of the line: the counter itself is word 0): 8 first tile start, 9 last tile arrival,
+        // developer timeline (tools/dev/tail_timeline.py), in the unused words 8..15 of the chain's own counter line (the
+        // counter is word 0: the stamps disturb the hand-off they time -- good for its shape, not for its duration):
+        // 8 first tile start, 9 last tile arrival,
         // 10 first role past its wait, 11 last role past its wait, 12 last role done, 13 first role start -- of the launches
         // with par = 1 since the last reset (the probe runs trajectories of three leapfrog steps: exactly one such launch)
         unsigned long long *stp = ch.tail + (size_t)(d.b0 + bz) * TAIL_STRIDE + 8;
