@@ -40,6 +40,8 @@ struct Dims {
     int sp_par;             // which of the two Work::sp / Work::gst buffers holds the current position
     int skew;               // test hook (seir_set_option SEIR_OPT_DEBUG_SKEW = 1..3): a third of the workgroups of every launch starts ~30 us late
     int aff_nb;             // 0 = natural grids (tile, chain); > 0 = 1-D grids of tiles*aff_nb blocks with chain <-> XCD affinity
+    int nlive;              // k_se_chunk, k_move_pair: > 0 = the grid is laid out for aff_nb / nbk chains but only the first nlive
+                            // exist (fewer than 8 chains in the 8-chain layout: every chain whole on one XCD); their blocks retire at once
     double nu, dt, rate_floor, car_half_logdet;
     double L_ei;            // log(1 - exp(-nu dt))
     double prior_const;     // parameter-free part of the summed prior log-densities

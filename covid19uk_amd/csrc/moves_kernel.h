@@ -1340,6 +1340,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     // whatever the number of chains; the closing launch has role 0 only
     const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;
     const int b = d.b0 + (int)blockIdx.x - slot * nbk, tid = threadIdx.x;
+    if (d.nlive > 0 && (int)blockIdx.x - slot * nbk >= d.nlive) return;             // a chain of the layout that does not exist
     if (slot >= nroles) {                                  // band workgroups (the highest block ids)
         const unsigned tok = ch.sweep[b] * 64u + (unsigned)lidx + 1u;
         const bool r1 = next.kind >= 0 && nroles >= 2, r2 = se_next.kind >= 0 && nroles == 3;

@@ -1074,6 +1074,7 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
     if ((int)blockIdx.x < n_tiles) {
         int bz, tile;
         xcd_affine(blockIdx.x, ntile, d.aff_nb, bz, tile);
+        if (d.nlive > 0 && bz >= d.nlive) return;      // a chain of the layout that does not exist
 #ifdef TAIL_STAMPS
         // developer timeline (tools/dev/tail_timeline.py), in the unused words 8..15 of the chain's own counter line (the
         // counter is word 0: the stamps disturb the hand-off they time -- good for its shape, not for its duration):
@@ -1095,6 +1096,7 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
     if (threadIdx.x >= WAVE) return;                   // a role is one wave
     const int L = (int)blockIdx.x - n_tiles;
     const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
+    if (d.nlive > 0 && bz >= d.nlive) return;
     const unsigned long long *cnt = ch.tail + (size_t)b * TAIL_STRIDE;
 #ifdef TAIL_STAMPS
     unsigned long long *stp = ch.tail + (size_t)b * TAIL_STRIDE + 8;

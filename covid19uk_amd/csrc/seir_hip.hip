@@ -1360,14 +1360,18 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         // chunk roles inside the gradient launch (k_se_chunk): 8 chains, one XCD each (checked at creation), the
         // XCD-affine grid, no graph capture in progress (the ticket counter does not care, but keep the two apart)
         const int ntile_se = d0.ntc * d0.nmt;
-        const bool tail = s->hmc_tail && s->xcd_local && nb % 8 == 0 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nb) &&
+        // fewer than 8 chains: the 8-chain layout with the missing chains' blocks retiring at once, so that every chain
+        // is still whole on one XCD (nbv = chains of the layout)
+        const int nbv = nb % 8 == 0 ? nb : (nb < 8 ? 8 : 0);
+        const bool tail = s->hmc_tail && s->xcd_local && nbv > 0 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nbv) &&
                           !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && ts_mode != 0;
         for (int i = 1; i < c.L; ++i) {
             l.d.sp_par = par;
             if (tail) {
                 Dims df = l.d;
-                df.aff_nb = nb;
-                const dim3 gf((unsigned)((ntile_se + per) * nb));      // tiles, then the chunk roles
+                df.aff_nb = nbv;
+                df.nlive = nbv != nb ? nb : 0;
+                const dim3 gf((unsigned)((ntile_se + per) * nbv));     // tiles, then the chunk roles
                 s->tail_count += (unsigned long long)ntile_se;         // what a chain's counter shows once this launch's tiles are in
                 const unsigned long long target = s->tail_count;
 #define LAUNCH_TAIL(TSM_, NTC_) hipLaunchKernelGGL((k_se_chunk<TSM_, NTC_>), gf, dim3(256), 0, st, df, ctx->c, ctx->w, c, s->ch, par, target)
@@ -1426,8 +1430,12 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             int cus = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
             const int nband_fit = (d.M + 15) / 16;                      // 16 rows per band workgroup: two per wave
-            const bool band_in_pair = s->moves_mode != 3 && s->xcd_local && nb % 8 == 0 && s->ngroups == 1 && !s->use_graph &&
-                                      (3 + nband_fit) * nb <= cus;
+            const int nbv = nb % 8 == 0 ? nb : (nb < 8 ? 8 : 0);          // as for k_se_chunk: the layout's chains
+            const bool band_in_pair = s->moves_mode != 3 && s->xcd_local && nbv > 0 && s->ngroups == 1 && !s->use_graph &&
+                                      (3 + nband_fit) * nbv <= cus;
+            const int nbk = band_in_pair ? nbv : nb;
+            Dims dp = d;
+            dp.nlive = band_in_pair && nbv != nb ? nb : 0;
             const int nband = band_in_pair ? nband_fit : 0;
             SamplerCfg cp = c;
             if (band_in_pair) cp.nrb_d = nband;                          // the band's partial sums: one pair per band workgroup
@@ -1439,8 +1447,8 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                     const bool pre = (s->moves_mode == 0 || s->moves_mode == 3) && pair + 1 < npairs;
                     const int nh = (half + 1) & 1, nscan = scan + (half == 1 ? 1 : 0);
                     const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : MoveSpec{-1, 0, 0, 0};
-                    hipLaunchKernelGGL(pair_fn, dim3(((pre ? 3 : 2) + nband) * nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, cp, s->ch,
-                                       se, nx, se_next, have_prev, have_pre, pbuf, nb, pair, s->pair_debug, nband);
+                    hipLaunchKernelGGL(pair_fn, dim3(((pre ? 3 : 2) + nband) * nbk), dim3(MVB), plds, st, dp, ctx->c, ctx->w, cp, s->ch,
+                                       se, nx, se_next, have_prev, have_pre, pbuf, nbk, pair, s->pair_debug, nband);
                     have_pre = pre ? 1 : 0;
                     pbuf ^= 1;
                     if (!band_in_pair)
