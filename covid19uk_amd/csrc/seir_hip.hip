@@ -1360,9 +1360,9 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         // chunk roles inside the gradient launch (k_se_chunk): 8 chains, one XCD each (checked at creation), the
         // XCD-affine grid, no graph capture in progress (the ticket counter does not care, but keep the two apart)
         const int ntile_se = d0.ntc * d0.nmt;
-        // fewer than 8 chains: the 8-chain layout with the missing chains' blocks retiring at once, so that every chain
-        // is still whole on one XCD (nbv = chains of the layout)
-        const int nbv = nb % 8 == 0 ? nb : (nb < 8 ? 8 : 0);
+        // not a multiple of 8 chains: the layout of the next multiple with the missing chains' blocks retiring at once,
+        // so that every chain is still whole on one XCD (nbv = chains of the layout)
+        const int nbv = (nb + 7) / 8 * 8;
         const bool tail = s->hmc_tail && s->xcd_local && nbv > 0 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nbv) &&
                           !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && ts_mode != 0;
         for (int i = 1; i < c.L; ++i) {
@@ -1430,7 +1430,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             int cus = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
             const int nband_fit = (d.M + 15) / 16;                      // 16 rows per band workgroup: two per wave
-            const int nbv = nb % 8 == 0 ? nb : (nb < 8 ? 8 : 0);          // as for k_se_chunk: the layout's chains
+            const int nbv = (nb + 7) / 8 * 8;                            // as for k_se_chunk: the layout's chains
             const bool band_in_pair = s->moves_mode != 3 && s->xcd_local && nbv > 0 && s->ngroups == 1 && !s->use_graph &&
                                       (3 + nband_fit) * nbv <= cus;
             const int nbk = band_in_pair ? nbv : nb;

@@ -508,9 +508,9 @@ def test_compact_event_trace_is_lossless_and_guards_its_range(api):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 3, 8, 16])
+@pytest.mark.parametrize("B", [1, 3, 8, 12, 16])
 def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
-    """hmc="chunk" with fewer than 8 chains (in the 8-chain layout) or a multiple of 8 (chain b on XCD b mod 8) runs the chunk roles of a leapfrog step inside the gradient launch (k_se_chunk: the
+    """hmc="chunk" (any number of chains, in the layout of the next multiple of 8: chain b on XCD b mod 8) runs the chunk roles of a leapfrog step inside the gradient launch (k_se_chunk: the
     last workgroups of a chain to arrive take the roles; hand-off through the XCD's L2) when the GPU places block ids
     congruent mod 8 on one XCD each; hmc="chunk-split" launches them separately.  Same arithmetic in the same order:
     every traced quantity must agree to the last bit, with and without workgroup skew."""
@@ -546,6 +546,7 @@ def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
                                             ("ni11", 1, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
                                             ("ni11", 5, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
                                             ("uk380", 2, dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5),
+                                            ("ni11", 11, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
                                             ("ni11", 16, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
                                             ("uk380", 8, dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5)])
 def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, B, cfg, eps):
