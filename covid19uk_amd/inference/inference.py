@@ -110,7 +110,7 @@ class Posterior:
             self._file = hdf5io.File(filename, "w")
             for name, shp in self.shapes.items():
                 self._file.create_dataset("/" + name, (self.num_samples,) + shp, self.dtypes.get(name, np.float64),
-                                          chunk_rows=burst if name == "samples/seir" else None)
+                                          raw=name == "samples/seir")
         else:
             self._file = None
             self._mem = {name: np.zeros((self.num_samples,) + shp, self.dtypes.get(name, np.float64))
@@ -120,6 +120,11 @@ class Posterior:
     def write(self, name, value, first_dim_offset):
         if self.use_h5:
             v = np.asarray(value)
+            if name == "samples/seir":
+                # the event tensor arrives as the device's integer counts (a strided view of the burst): converted to
+                # the file's float64 and written at its file address by a few threads (hdf5io.write_rows_parallel)
+                self._file.write_rows_parallel("/" + name, v, offset=first_dim_offset)
+                return
             if v.dtype != np.float64 and v.dtype.kind in "iu" and v.nbytes > (1 << 20):
                 # the event tensor arrives as the device's integer counts (a strided view of the burst); it is
                 # converted to the file's float64 in ONE pass into a buffer kept between bursts -- a fresh
