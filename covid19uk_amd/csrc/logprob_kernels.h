@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const 
 }
 
 // ---------------------------------------------------------------------------
-// k_eval_all: the whole stateless evaluation in ONE launch (8 chains, one XCD each -- the XCD-local hand-off of
+// k_eval_all: the whole stateless evaluation in ONE launch (chain b on XCD b mod 8 -- the XCD-local hand-off of
 // sampler_kernels.h, k_se_chunk: producers' stores are in the XCD's L2 before they count themselves in, consumers
 // have higher block ids, wait on the chain's counter and read nothing they or a neighbour on their CU could have read
 // before it was written).  Block id mod 8 = chain in every segment (all segment sizes are multiples of 8):
@@ -1294,7 +1294,9 @@ __global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const 
 //   parameter block, the tiles' state parts -> counter A -> tiles (X, KS, ea, eb), fold (per-block I->R partials)
 //   tiles, row constants, fold -> counter B -> finish
 // Against the three-launch form it saves two launch ramps and boundaries and the idle time between them; same
-// arithmetic, same bits.  cnt: [8][2 TAIL-like lines]: A at cnt[chain * 32], B at cnt[chain * 32 + 16].
+// arithmetic, same bits.  cnt: [chains][2 TAIL-like lines]: A at cnt[chain * 32], B at cnt[chain * 32 + 16].
+// Any number of chains in the layout of the next multiple of 8 (Dims::aff_nb, nlive as in k_se_chunk); the host uses
+// it while every tile workgroup of the launch can be resident (a tile waits for its chain's state while it holds a slot).
 // ---------------------------------------------------------------------------
 constexpr int EVC_STRIDE = 32;          // 64-bit words per chain: counters A and B in lines of their own
 __device__ __forceinline__ void evc_arrive(unsigned long long *p_) {
@@ -1317,15 +1319,16 @@ void k_eval_all(Dims d, Consts c, Work w, const double *__restrict__ events, con
                 double *__restrict__ logp, double *__restrict__ grad, unsigned long long *cnt,
                 unsigned long long targetA, unsigned long long targetB, int *err, int do_finish) {
 #ifdef EVAL_STAMPS
-#define ESTAMP(i) do { if (threadIdx.x == 0 && chain == 0 && tile_or0 == 0) cnt[8 * EVC_STRIDE + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ESTAMP(i) do { if (threadIdx.x == 0 && chain == 0 && tile_or0 == 0) cnt[NB * EVC_STRIDE + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ESTAMP(i) do {} while (0)
 #endif
-    constexpr int NB = 8;
+    const int NB = d.aff_nb;                                // chains of the layout: a multiple of 8
     const int per = d.ntc * d.nmt, ncb = d.Tp / WAVE;
     const int nP = NB, nT = per * NB, nC = d.nrb_scan * NB, nR = ncb * NB;
     int L = blockIdx.x;
-    const int chain = L & (NB - 1);
+    const int chain = L % NB;                               // every segment is a multiple of NB blocks long
+    if (d.nlive > 0 && chain >= d.nlive) return;            // a chain of the layout that does not exist
     unsigned long long *cA = cnt + (size_t)chain * EVC_STRIDE, *cB = cA + EVC_STRIDE / 2;
     if (L < nP) {                                           // the chain's parameter tables
         __shared__ double sh[4];

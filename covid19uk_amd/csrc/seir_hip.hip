@@ -484,13 +484,15 @@ static void launch_finish_fused(seir_ctx *ctx, const LaunchCfg &l, const double 
 template <int TN>
 static int launch_eval_all(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, const double *events_dev,
                            double *logp_dev, double *grad_dev) {
+    const int nbv = (l.nb + 7) / 8 * 8;
     if (!ctx->eval_cnt) {
-        int rc = dev_alloc(ctx, &ctx->eval_cnt, (size_t)8 * EVC_STRIDE + 16);
+        int rc = dev_alloc(ctx, &ctx->eval_cnt, (size_t)((ctx->Bmax + 7) / 8 * 8) * EVC_STRIDE + 16);
         if (!rc) rc = dev_alloc(ctx, &ctx->eval_err, 1);
         if (rc) return rc;
     }
     Dims d = fused_dims<TN>(l);
-    d.aff_nb = 0;
+    d.aff_nb = nbv;
+    d.nlive = nbv != l.nb ? l.nb : 0;
     const int per = d.ntc * d.nmt, ncb = d.Tp / WAVE;
     ctx->eval_a += (unsigned long long)(per + 1);                       // per chain: the tiles' state parts + the parameter block
     ctx->eval_b += (unsigned long long)(per + d.nrb_scan + ncb);        //            tiles + row-constant blocks + I->R fold blocks
@@ -501,7 +503,7 @@ static int launch_eval_all(seir_ctx *ctx, const LaunchCfg &l, const double *u_de
         (void)hipFuncSetAttribute((const void *)k_eval_all<false, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const dim3 grid((unsigned)((1 + per + d.nrb_scan + ncb + 1) * 8));
+    const dim3 grid((unsigned)((1 + per + d.nrb_scan + ncb + 1) * nbv));
     // the reduction block runs inside the launch for value-only calls; with the gradient it is its own launch (measured:
     // the gradient assembly takes 12.7 us as the last block of this large kernel against 4.8 us in k_finish -- 59.2 us
     // per batch against 56.9)
@@ -562,9 +564,20 @@ extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, 
     const bool f32 = ctx->opt_gemm_f32 && ctx->c.Cstar32 && ctx->w.Xn32;
     if (ctx->opt_eval_form != 1 && !f32) {
         bool one = false;
-        if (ctx->opt_eval_form == 0 && B == 8 && (l.affinity & 1)) {
-            if (ctx->xcd_local < 0) ctx->xcd_local = probe_xcd_local(ctx->stream) ? 1 : 0;
-            one = ctx->xcd_local == 1;
+        if (ctx->opt_eval_form == 0 && B % 8 == 0 && (l.affinity & 1)) {
+            // one launch for multiples of 8 chains (a single chain confined to one XCD loses more than the launches cost:
+            // 46 / 54 us against 38 / 45, level at 4; 12 chains in the layout of 16 cost nearly what 16 do) while the parameter blocks and every tile workgroup
+            // fit the chip at once (two workgroups of k_eval_all per CU: 128 VGPRs x 8 waves, <= 54 KB of LDS): UK-380
+            // up to 16 chains (83 / 92 us against 87 / 93 in three launches)
+            const int tn = d.Tp % 96 == 0 ? 96 : 64;
+            const int per1 = (d.Tp / tn) * (d.Mp / GEMM_TM);
+            const int nbv = (B + 7) / 8 * 8;
+            int cus = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            if ((1 + per1) * nbv <= 2 * cus) {
+                if (ctx->xcd_local < 0) ctx->xcd_local = probe_xcd_local(ctx->stream) ? 1 : 0;
+                one = ctx->xcd_local == 1;
+            }
         }
         if (one) {
             rc = d.Tp % 96 == 0 ? launch_eval_all<96>(ctx, l, u_dev, events_dev, logp_dev, grad_dev)

@@ -321,16 +321,18 @@ def test_fp32_contraction_needs_128_tiles(Model):
 
 
 @pytest.mark.parametrize("name,seed", [("ni11", 23), ("uk380", 24)])
-def test_one_launch_and_three_launch_evaluations_give_the_same_bits(Model, name, seed):
-    """With 8 chains the default form runs state scan, contraction tiles and reduction as ONE launch (k_eval_all:
+@pytest.mark.parametrize("B", [8, 16])
+def test_one_launch_and_three_launch_evaluations_give_the_same_bits(Model, name, seed, B):
+    """With a multiple of 8 chains whose tile workgroups all fit the chip (UK-380: 8 and 16; chain b on XCD b mod 8) the
+    default form runs state scan, contraction tiles and reduction as ONE launch (k_eval_all:
     counters in the chain's own L2 line, consumers behind producers in block order) where the GPU places block ids
     congruent mod 8 on one XCD each; "three-launch" forces the separate launches.  Same code, same order: same bits,
     call after call (the counters run on), with workgroup skew, and for value-only calls."""
     case = H.build_case(name, seed, alpha_t_sd=0.005)
-    u, ev = _batch(case, 8, seed)
+    u, ev = _batch(case, B, seed)
     res = {}
     for form, skew in (("three-launch", 0), ("fused", 0), ("fused", 2)):
-        with Model(case["cov"], case["init"], max_chains=8) as model:
+        with Model(case["cov"], case["init"], max_chains=B) as model:
             model.set_option(eval_form=form, debug_skew=skew)
             out = []
             for rep in range(3):
