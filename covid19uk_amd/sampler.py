@@ -283,7 +283,8 @@ class ChainSampler:
 
     def xcd_local(self) -> bool:
         """True if workgroups with ids congruent mod 8 share an XCD on this GPU (probed at creation): the condition for
-        the chunk roles of an HMC step to run inside the gradient launch (hmc="chunk" with 8 chains)."""
+        the chunk roles of an HMC step to run inside the gradient launch (hmc="chunk") and the band workgroups inside
+        the pair launch (moves="paired")."""
         return bool(self._lib.seir_sampler_xcd_local(self._s))
 
     def pair_timeouts(self) -> np.ndarray:

@@ -143,7 +143,7 @@ class SeirModel:
 
     def set_option(self, debug_skew=None, xcd_affinity=None, gemm_f32=None, eval_form=None):
         """Launch options of the context (seir_set_option): the workgroup-timing test hook, the
-        chain <-> XCD block mapping and the launch form of `log_prob_dev` ("fused" -- one launch for 8 chains where the GPU
+        chain <-> XCD block mapping and the launch form of `log_prob_dev` ("fused" -- one launch for 8 or 16 chains where the GPU
         allows it, else three -- | "three-launch" | "four-launch"; none of
         them changes a result beyond summation order), and `gemm_f32`: the mobility contraction
         with fp32 operands on the fp32 matrix instruction (BASELINE config 5; ~1e-8 relative on the log-prob)."""

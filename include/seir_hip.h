@@ -119,9 +119,9 @@ void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context
  *                            ceil64(M) and ceil64(T) to be multiples of 128.
  *   SEIR_OPT_EVAL_FORM       launch form of seir_log_prob_dev (speed only): 0 (default) = the S->E term evaluated on the
  *                            contraction's accumulators and the row constants beside the matrix-core tiles, as ONE
- *                            launch for a batch of 8 chains on a GPU that places block ids congruent mod 8 on one XCD
- *                            each (state, tiles and reduction hand over through that XCD's L2), as three launches
- *                            otherwise; 1 = the four-launch form (scan, contraction, S->E tiles, reduction); 2 = always
+ *                            launch for a batch of 8 or 16 chains (a multiple of 8 whose tile workgroups all fit the chip) on a
+ *                            GPU that places block ids congruent mod 8 on one XCD each (state, tiles and reduction hand
+ *                            over through that XCD's L2), as three launches otherwise; 1 = the four-launch form (scan, contraction, S->E tiles, reduction); 2 = always
  *                            three launches.  0 and 2 give the same bits
  * Options are read when a launch is enqueued (for a sampler using graph replay: at capture). */
 enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2, SEIR_OPT_EVAL_FORM = 3 };
@@ -194,11 +194,12 @@ typedef struct {
                                        -- kept as a cross-check; 2: paired launches without the pre-draw; 3: as 0 with
                                        the band part of the E->I-type log-ratio always as its own launch
                                        (k_move_delta).  0 and 2 let workgroups of the pair launch evaluate it where
-                                       all of a chain's workgroups share an XCD (8 chains, seir_sampler_xcd_local).
+                                       all of a chain's workgroups share an XCD (seir_sampler_xcd_local; any number of chains in the
+                                       layout of the next multiple of 8, while every workgroup of the launch fits the chip).
                                        Same draws in all four */
     int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks, run by the last workgroups of the
                                        gradient launch itself (k_se_chunk) when all of a chain's workgroups share
-                                       an XCD (8 chains per launch, checked through XCC_ID at creation), otherwise
+                                       an XCD (chain b's block ids are congruent to b mod 8; checked through XCC_ID at creation), otherwise
                                        as their own launch (k_hmc_chunk); 1: every step by the single-workgroup
                                        kernel; 2: chunks always as their own launch (the cross-check of 0: same
                                        bits).  0/2 against 1: same draws up to summation order */
