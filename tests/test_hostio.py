@@ -29,6 +29,38 @@ def test_hdf5_roundtrip(tmp_path):
         assert list(f.read("/names")) == [b"ab", b"cdef"]
 
 
+def test_rows_written_at_their_file_address_read_back_through_the_library(tmp_path):
+    """samples/seir is a contiguous dataset, allocated at creation and never filled, whose row blocks are converted and
+    written with pwrite at H5Dget_offset by several threads (hdf5io.write_rows_parallel).  What the library reads back
+    must be what was handed over: integer sources of either width, strided views of a burst buffer, any block offset
+    and thread count; datasets beside it written through H5Dwrite before and after; blocks that do not fit refused."""
+    p = str(tmp_path / "raw.h5")
+    rng = np.random.default_rng(5)
+    n, shape = 23, (7, 11, 3)
+    full = rng.integers(0, 60000, size=(n,) + shape)
+    with hdf5io.File(p, "w") as f:
+        f.create_dataset("/samples/psi", (n,), np.float64)
+        f.create_dataset("/samples/seir", (n,) + shape, np.float64, raw=True)
+        f.create_dataset("/results/acc", (n,), np.int8)
+        f.write("/samples/psi", np.arange(n) * 0.5)
+        burst = np.zeros((n, 2) + shape, np.uint16)            # [draw][chain]...: a chain's rows are a strided view
+        burst[:, 1] = full
+        f.write_rows_parallel("/samples/seir", burst[0:5, 1], offset=0, threads=3)
+        f.write_rows_parallel("/samples/seir", full[5:6].astype(np.int32), offset=5, threads=8)
+        f.write_rows_parallel("/samples/seir", burst[6:23, 1], offset=6, threads=1)
+        f.write("/results/acc", (np.arange(n) % 2).astype(np.int8))
+        with pytest.raises(ValueError):
+            f.write_rows_parallel("/samples/seir", burst[0:5, 1], offset=20)
+        f.write_rows_parallel("/samples/psi", np.full(2, 7.0), offset=3)      # not a raw dataset: the ordinary path
+    with hdf5io.File(p, "r") as f:
+        got = f.read("/samples/seir")
+        assert got.dtype == np.float64 and np.array_equal(got, full.astype(np.float64))
+        psi = f.read("/samples/psi")
+        assert psi[3] == 7.0 and psi[4] == 7.0 and psi[5] == 2.5
+        assert np.array_equal(f.read("/results/acc"), np.arange(n) % 2)
+        assert np.array_equal(f.read_rows("/samples/seir", 4, 3, 2), got[4:9:2])      # start, count, stride
+
+
 def test_inference_data_roundtrip(tmp_path):
     cov = synth.make_covariates("ni11")
     ev, _, _ = synth.simulate_epidemic(cov)
