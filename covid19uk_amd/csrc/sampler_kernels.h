@@ -89,9 +89,11 @@ struct Chains {
                                                          //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
     unsigned *done;                                      // [B][2 TAIL_STRIDE] k_move_pair with band workgroups: token of the launch whose
                                                          //     role r has finished, at [b][r] (a chain's three tokens in its own line)
-    unsigned long long *tail;                            // [B][TAIL_STRIDE] k_se_chunk: tiles of the chain that have arrived, over all
-                                                         //     launches -- one counter per 128-byte line: eight chains' counters in
-                                                         //     one line made every ticket a cross-XCD transaction (+14 us per launch)
+    unsigned long long *tail;                            // [B][TAIL_STRIDE] k_se_chunk: tiles of the chain that have arrived, over
+                                                         //     all launches -- one counter per 128-byte line: eight chains' counters in
+                                                         //     one line made every ticket a cross-XCD transaction (+14 us per launch);
+                                                         //     then [B][TAIL_FLAG_STRIDE]: the count at which the chain's last tile raised
+                                                         //     the flag the roles poll
     unsigned *hand2;                                     // [B] the same token for role 2 (pre-drawn S->E-type proposal)
     Move *mvs;                                           // [2][B] S->E-type proposal pre-drawn for the next launch (k_move_pair, role 2)
     double *DownS;                                       // [2][B][2] its own-rows log-ratio {theta, const}
@@ -1055,8 +1057,9 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
 // load that does not depend on the tiles while they are still running, most of its memory latency as well.
 // Grid: the XCD-affine tile grid of k_se (ntile x nb blocks, nb a multiple of 8) followed by (ntc + Mp/64) x nb role
 // blocks (block id mod 8 = chain mod 8 there too).  A tile workgroup evaluates its tile exactly as k_se does and then counts itself in on the chain's
-// counter (Chains::tail, one cache line per chain); a role workgroup (one wave) issues its independent loads, waits
-// until the counter shows `target` -- every tile of the chain, of every launch so far -- and runs the role.  Blocks
+// counter (Chains::tail, one cache line per chain); the tile that brings the counter to `target` -- every tile of the
+// chain, of every launch so far -- raises the chain's flag (a line of its own); a role workgroup (one wave) issues its
+// independent loads, waits for the flag and runs the role.  Blocks
 // are dispatched in id order, so a role is placed only after every tile has been: it can never hold a slot that an
 // unplaced tile needs, whatever the residency.
 // Memory: the hand-off uses NO agent-scope release/acquire (an L2 write-back / invalidate costs 7-30 us here,
@@ -1066,7 +1069,11 @@ __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, Sa
 // itself in, and the roles read the partial sums past their L1.  The roles write the NEXT position's tables (ea,
 // eb, psi ...) only after every tile of the chain has counted in, i.e. has long read the current ones.  Results are
 // bit-identical to k_se followed by k_hmc_chunk.
-constexpr int TAIL_BACKOFF = 60;     // x 64 cycles
+constexpr int TAIL_BACKOFF = 30;     // x 64 cycles
+// a chain's flag sits 4 KB + one line from the next chain's and well away from its counter: in the line next to the
+// counters' (stride 16) the polls still cost 6 us per sweep -- presumably the same L2 channel
+constexpr int TAIL_FLAG_STRIDE = 528;
+#define TAIL_FLAG_AT(B_, b_) ((size_t)(B_) * TAIL_STRIDE + (size_t)(b_) * TAIL_FLAG_STRIDE)
 template <int TSM, int NTC>
 __global__ __launch_bounds__(256)
 void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsigned long long target) {
@@ -1086,8 +1093,14 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
 #endif
         se_tile<true, 1, TSM>(d, c, w, tile % d.ntc, tile / d.ntc, bz);
         __syncthreads();                               // vmcnt(0): this tile's partial sums are in the XCD's L2
-        if (threadIdx.x == 0)
-            __hip_atomic_fetch_add(ch.tail + (size_t)(d.b0 + bz) * TAIL_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            const unsigned long long old = __hip_atomic_fetch_add(ch.tail + (size_t)(d.b0 + bz) * TAIL_STRIDE, 1ull, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
+            // the last tile of the chain raises the chain's flag, in a line of its own: the roles poll that one -- polling
+            // the counter's line, which 144 tiles are still adding to, cost 11 us per sweep
+            if (old + 1 == target)
+                __hip_atomic_store(ch.tail + TAIL_FLAG_AT(s.B, d.b0 + bz), target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef TAIL_STAMPS
         if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_max(stp + 1, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -1097,19 +1110,20 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
     const int L = (int)blockIdx.x - n_tiles;
     const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
     if (d.nlive > 0 && bz >= d.nlive) return;
-    const unsigned long long *cnt = ch.tail + (size_t)b * TAIL_STRIDE;
+    const unsigned long long *flag = ch.tail + TAIL_FLAG_AT(s.B, b);   // raised by the chain's last tile
 #ifdef TAIL_STAMPS
     unsigned long long *stp = ch.tail + (size_t)b * TAIL_STRIDE + 8;
     if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_min(stp + 5, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     hmc_chunk_role<NTC, true>(d, c, w, s, ch, par, role, b, [&] {
         int spins = 0;
-        // back off before the first look at the counter: since the roles fit beside all the tiles (96 VGPRs, five waves
-        // per SIMD) they are resident from the start of the launch, and 96 waves polling the lines the tiles count
-        // themselves in on made the whole launch slower than at four waves per SIMD (12.7 us against 12.1); with the
-        // first ~1.8 us slept through -- no tile phase of this size is shorter -- it is the faster form (11.8)
+        // back off before the first look: since the roles fit beside all the tiles (96 VGPRs, five waves per SIMD) they
+        // are resident from the start of the launch, and no tile phase of this size is shorter than the ~0.9 us slept
+        // through.  (While the roles still polled the counters' own lines, 96 polling waves made the launch slower than
+        // at four waves per SIMD, 12.7 us against 12.1, and a 1.8 us sleep was worth 0.9 us; with the flag lines the
+        // launch takes 11.0 us and the sleep is worth little.)
         if (ntile >= 32) __builtin_amdgcn_s_sleep(TAIL_BACKOFF);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 22)) {                 // ~0.1 s: never seen; counted like k_move_pair's time-outs, no hang
                 if (threadIdx.x == 0) ch.late[b] += 1;

@@ -1074,7 +1074,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.mvsel, (size_t)2 * B);
     S_ALLOC(ch.hand, (size_t)B);
     S_ALLOC(ch.late, (size_t)B);
-    S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE);
+    S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
     S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
     S_ALLOC(ch.hand2, (size_t)B);
     S_ALLOC(ch.mvs, (size_t)2 * B);
