@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 MCMC_CONFIG = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5)  # example_config.yaml:26-30
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, chip-level parameters
 F64_MFMA_PEAK_TFLOPS = 78.6     # dense fp64 matrix peak (v_mfma_f64_16x16x4_f64), same guide
+F32_MFMA_PEAK_TFLOPS = 157.3    # dense fp32 matrix peak (v_mfma_f32_32x32x2_f32), same guide
 
 
 def parse():
@@ -41,7 +42,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="uk380", choices=["uk380", "ni11"])
+    ap.add_argument("--workload", default="uk380", choices=["uk380", "ni11", "syn2048"],
+                    help="uk380 = the configuration BASELINE.json's metric is quoted on (default, the headline); syn2048 = "
+                         "BASELINE config 5 (2048 regions x 730 days, fp32 MFMA mobility contraction)")
+    ap.add_argument("--gemm-f32", type=int, default=None, choices=[0, 1],
+                    help="mobility contraction F = Cstar.X in fp32 MFMA (default: 1 for syn2048 -- BASELINE config 5 names "
+                         "it -- and 0 otherwise: the fp64 MFMA form)")
     ap.add_argument("--chains-per-gpu", type=int, default=8)
     ap.add_argument("--adapt-sweeps", type=int, default=60, help="untimed dual-averaging sweeps during setup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,15 +116,35 @@ def cpu_baseline(cov, init, events, u0, n_sweeps, seed, cores=None):
                       f"{cores} threads), {ch.n_evals} full log-prob evaluations, same workload"}
 
 
+def self_launch(n):
+    """Run this script as n ranks on this node; returns the job's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so_:
+        so_.bind(("127.0.0.1", 0))
+        port = so_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and not (world == 1 and a.gpus == 1):
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as a fresh child job (one process per GPU under
+        # torch.distributed.run, RCCL over xGMI) BEFORE anything here touches the GPU, relay its output (rank 0
+        # prints the JSON line) and leave with its exit code.  Never an exec of a process that has used the GPU.
+        sys.exit(self_launch(a.gpus))
+    if world != a.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
 
     import torch
@@ -155,12 +181,19 @@ def main():
     ev0 = np.stack([events] * B)
     K, W = a.steps, a.warmup
 
+    syn = a.workload == "syn2048"
+    f32 = bool(a.gemm_f32) if a.gemm_f32 is not None else syn
+    if syn:
+        # the extras below are UK-380 context for the headline number; at SYN-2048 they would only cost time
+        a.no_egress = a.no_chains_scaling = a.no_cli = True
     model = SeirModel(cov, init, max_chains=B, device=local)
+    if f32:
+        model.set_option(gemm_f32=True)
     burst = max(1, min(K, 50))                    # sweeps per burst of the overlapped-egress measurement
     sampler = ChainSampler(model, MCMC_CONFIG, B, seed=a.seed, first_chain_id=first_chain,
                            trace_capacity=max(K, 2 * burst), record_events="u16")
     sampler.set_state(u0, ev0)
-    sampler.set_kernel(step_size=2e-5)
+    sampler.set_kernel(step_size=2e-6 if syn else 2e-5)
     # setup (untimed): a short dual-averaging window, then pool the step size over ALL chains
     # of the job (the optional cross-chain gather of BASELINE.json config 4: RCCL all_gather).
     if a.adapt_sweeps > 0:
@@ -289,6 +322,8 @@ def main():
     # independent evaluations issued on several contexts (one stream each) overlap: the HBM-bound state pass of one
     # runs under the matrix-core tiles of another.  Same call, same batch, three contexts used in turn.
     try:
+        if syn:
+            raise RuntimeError("skipped at SYN-2048")
         extra = [SeirModel(cov, init, max_chains=B, device=local) for _ in range(2)]
         ctxs = [model] + extra
         lps = [lp] + [torch.empty_like(lp) for _ in extra]
@@ -312,7 +347,7 @@ def main():
     # the stateless evaluation (what the reference calls 37x per draw) against ITS bound: the larger of the
     # HBM time of the algorithmic bytes and the fp64 matrix time of the mobility contraction 2 M^2 T per chain
     t_hbm = alg_bytes / (HBM_PEAK_GBPS * 1e9)
-    t_mfma = 2.0 * M * M * T * B / (F64_MFMA_PEAK_TFLOPS * 1e12)
+    t_mfma = 2.0 * M * M * T * B / ((F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS) * 1e12)
     t_eval = B / evals["value_and_grad"]
     stateless = {"path": "seir_log_prob_dev, value + gradient, 8 chains: k_eval_all [parameter tables | tiles: their share of the state "
                          "scan, then the fp64 MFMA contraction with the S->E term as epilogue | row constants | I->R fold] with XCD-local "
@@ -324,13 +359,37 @@ def main():
                  "frac_3_contexts": (max(t_hbm, t_mfma) * evals["value_and_grad_3_contexts"] / B)
                                     if "value_and_grad_3_contexts" in evals else None,
                  "achieved": (2.0 * M * M * T * B / t_eval / 1e12) if t_mfma > t_hbm else alg_bytes / t_eval / 1e9,
-                 "peak": F64_MFMA_PEAK_TFLOPS if t_mfma > t_hbm else HBM_PEAK_GBPS,
+                 "peak": (F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS) if t_mfma > t_hbm else HBM_PEAK_GBPS,
                  "unit": "TFLOP/s" if t_mfma > t_hbm else "GB/s"}
     try:
         stateless["three_launch_form_kernels_us"] = {n: 1e3 * model.time_kernel(n, B, 50) for n in ("state", "tiles_grad", "finish_fused")}
         stateless["four_launch_form_kernels_us"] = {n: 1e3 * model.time_kernel(n, B, 50) for n in ("scan", "gemm", "se_grad", "finish")}
     except Exception as e:                                  # timing hook only
         stateless["kernels_us"] = str(e)
+
+    # BASELINE config 5: the mobility contraction F = Cstar . X (model_spec.py:258-263) on the matrix cores, both
+    # operand types, timed stand-alone on the context stream (HIP events) against the dense MFMA peak of the type
+    contraction = None
+    if syn:
+        contraction = {}
+        flops = 2.0 * M * M * T * B
+        for name, on, peak in (("f32", True, F32_MFMA_PEAK_TFLOPS), ("f64", False, F64_MFMA_PEAK_TFLOPS)):
+            model.set_option(gemm_f32=on)
+            model.log_prob_dev(ut, evt, lp, gr)            # the scan writes the operand of this type
+            model.sync()
+            ms_g = model.time_kernel("gemm", B, 20)
+            contraction[name] = {"kernel": "k_gemm_f32 (v_mfma_f32_32x32x2_f32, 128 x 128 tiles)" if on
+                                           else "k_gemm<64> (v_mfma_f64_16x16x4_f64, 64 x 64 tiles)",
+                                 "bound": "mfma", "mean_launch_us": 1e3 * ms_g, "algorithmic_flops_per_launch": flops,
+                                 "achieved": flops / (ms_g * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                 "frac": flops / (ms_g * 1e-3) / 1e12 / peak, "traffic": None}
+            model.log_prob_dev(ut, evt, lp, gr)
+            model.sync()
+            model.timer_start()
+            for _ in range(20):
+                model.log_prob_dev(ut, evt, lp, gr)
+            contraction[name]["log_prob_grad_evals_per_sec"] = B * 20 / (model.timer_stop() * 1e-3)
+        model.set_option(gemm_f32=f32)
 
     # context for the headline number (N=1 only, not part of `value`): the same sweep with more
     # chains resident on this GPU -- at 8 chains the sweep is bound by its dependent-launch chain,
@@ -395,14 +454,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "posterior samples/sec, 380-LAD UK SEIR" if a.workload == "uk380"
-                      else "posterior samples/sec, 11-LAD NI SEIR",
+            "metric": {"uk380": "posterior samples/sec, 380-LAD UK SEIR", "ni11": "posterior samples/sec, 11-LAD NI SEIR",
+                       "syn2048": "posterior samples/sec, synthetic 2048-region x 730-day SEIR"}[a.workload],
             "value": world * B * K / elapsed,
             "unit": "posterior samples/sec",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64 (mobility contraction: fp32 MFMA)" if f32 else "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload}: M={M} LADs x T={T} days, P={P} parameters",
                        "chains_per_gpu": B, "chains_total": world * B,
                        "sweep": "HMC(16 leapfrogs) + 5 x [S->E move, E->I move, S->E occult, E->I occult]",
@@ -433,9 +492,16 @@ def main():
             out["cli_samples_per_sec"] = cli
         if scaling:
             out["chains_per_gpu_scaling"] = scaling
+        if contraction:
+            # at SYN-2048 the line's `roofline` is the matrix-core contraction BASELINE config 5 names; the sweep's own
+            # dominant kernel (HBM-bound, as at UK-380) stays alongside
+            out["roofline_sweep_kernel"] = out["roofline"]
+            out["roofline"] = contraction["f32" if f32 else "f64"]
+            out["contraction"] = contraction
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed)
-            out["cpu_baseline_1core"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed, cores=1)
+            out["cpu_baseline"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps or (2 if syn else 0), a.seed)
+            if not syn:       # one core would need minutes per sweep at this size
+                out["cpu_baseline_1core"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed, cores=1)
         print(json.dumps(out), flush=True)
     if scaling is None:
         sampler.close()

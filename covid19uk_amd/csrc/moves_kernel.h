@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     const int r_lo = bx * rpb, r_hi = min(d.M, r_lo + rpb);
     // ---- the update accepted in this launch (token 4, early in the authoritative role): its descriptor, and what its F
     // band needs for this workgroup's rows -- coefficients and the F values themselves (nobody writes F but this code)
-    if (tid == 0) wait_token(done + 4, token, ch.late + b);
+    if (tid == 0) wait_token(done + 4, token, ch.late + ch.late_fatal + b);
     __syncthreads();
     move_copy_l2(&fp, ch.fpend + b, 128);
     __syncthreads();
@@ -1203,9 +1203,9 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     // and, in the rare launch in which a row conflict made the authoritative role draw it again (Chains::mvsel, known
     // with the last token), evaluated again for the re-drawn one.
     if (tid == 0) {
-        wait_token(done + 5, token, ch.late + b);
+        wait_token(done + 5, token, ch.late + ch.late_fatal + b);
         // the speculative role publishes its descriptor (token 3) well before it is done (token 1)
-        if (has_r1) wait_token(done + 3, token, ch.late + b);
+        if (has_r1) wait_token(done + 3, token, ch.late + ch.late_fatal + b);
     }
     __syncthreads();
     move_copy_l2(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     };
     double dth = evaluate(mvA);
     if (tid == 0) {
-        wait_token(done + 0, token, ch.late + b);
+        wait_token(done + 0, token, ch.late + ch.late_fatal + b);
         mv_sel = ld_l2(ch.mvsel + (size_t)buf * s.B + b);
     }
     __syncthreads();
@@ -1289,8 +1289,8 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
         out[1] = 0.0;
         // the F band: once nobody reads F any more
         if (has_fp) {
-            if (has_r1) wait_token(done + 1, token, ch.late + b);
-            if (has_r2) wait_token(done + 2, token, ch.late + b);
+            if (has_r1) wait_token(done + 1, token, ch.late + ch.late_fatal + b);
+            if (has_r2) wait_token(done + 2, token, ch.late + ch.late_fatal + b);
         }
     }
     if (!has_fp) return;

@@ -85,7 +85,11 @@ struct Chains {
     Move *fpend;                                         // [B] accepted E->I-type update whose F band is still to be applied (valid = 1)
     Move *mvfix;                                         // [2][B] E->I-type proposal re-drawn after a row conflict (k_move_pair)
     unsigned *hand;                                      // [B] k_move_pair: token of the launch whose role 1 has its totals
-    unsigned *late;                                      // [B] k_move_pair: launches whose role 0 gave up waiting for a speculative role
+    unsigned *late;                                      // [2][B] time-outs of in-launch waits.  [0][b]: k_move_pair launches whose role 0 gave up
+                                                         // waiting for a speculative role -- benign, it draws the proposal itself and the
+                                                         // traces are the same; [1][b] (offset late_fatal = B): waits that cannot be recovered
+                                                         // from (band tokens, k_se_chunk's tile flag): the workgroup went on without its data
+    int late_fatal;
                                                          //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
     unsigned *done;                                      // [B][2 TAIL_STRIDE] k_move_pair with band workgroups: token of the launch whose
                                                          //     role r has finished, at [b][r] (a chain's three tokens in its own line)
@@ -1126,7 +1130,7 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 22)) {                 // ~0.1 s: never seen; counted like k_move_pair's time-outs, no hang
-                if (threadIdx.x == 0) ch.late[b] += 1;
+                if (threadIdx.x == 0) ch.late[ch.late_fatal + b] += 1;
                 break;
             }
         }

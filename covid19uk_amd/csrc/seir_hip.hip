@@ -59,6 +59,7 @@ struct seir_ctx {
     unsigned long long *eval_cnt = nullptr;   // [8][EVC_STRIDE] k_eval_all's counters
     int *eval_err = nullptr;          // k_eval_all: waits that timed out
     unsigned long long eval_a = 0, eval_b = 0;   // what a chain's counters A and B show after the launches so far
+    int eval_nb = -1;                            // batch size of those launches (another size: counters and targets start over)
     std::vector<float> cstar32_host;        // fp32 copy of the padded Cstar, uploaded when the option is first set
 };
 
@@ -494,6 +495,16 @@ static int launch_eval_all(seir_ctx *ctx, const LaunchCfg &l, const double *u_de
     d.aff_nb = nbv;
     d.nlive = nbv != l.nb ? l.nb : 0;
     const int per = d.ntc * d.nmt, ncb = d.Tp / WAVE;
+    if (ctx->eval_nb != l.nb) {
+        // the counters are per chain and the targets one running total per context: a batch of another size leaves the
+        // chains that sat out behind the target (they would wait for the time-out and go on without their producers'
+        // data) -- start all of them from zero again, in stream order
+        if (hipMemsetAsync(ctx->eval_cnt, 0, sizeof(unsigned long long) * ((size_t)((ctx->Bmax + 7) / 8 * 8) * EVC_STRIDE + 16),
+                           l.st) != hipSuccess)
+            return fail(SEIR_ERR_DEVICE, "resetting the evaluation hand-off counters failed");
+        ctx->eval_a = ctx->eval_b = 0;
+        ctx->eval_nb = l.nb;
+    }
     ctx->eval_a += (unsigned long long)(per + 1);                       // per chain: the tiles' state parts + the parameter block
     ctx->eval_b += (unsigned long long)(per + d.nrb_scan + ncb);        //            tiles + row-constant blocks + I->R fold blocks
     const size_t lds = eval_all_lds_bytes<TN>(d);
@@ -1073,7 +1084,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.mvfix, (size_t)2 * B);
     S_ALLOC(ch.mvsel, (size_t)2 * B);
     S_ALLOC(ch.hand, (size_t)B);
-    S_ALLOC(ch.late, (size_t)B);
+    S_ALLOC(ch.late, (size_t)2 * B);
+    ch.late_fatal = B;
     S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
     S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
     S_ALLOC(ch.hand2, (size_t)B);
@@ -1544,12 +1556,18 @@ extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
 // trusted -- the next read of the trace fails loudly instead of delivering them.
 static int check_handoffs(seir_sampler *s) {
     if (s->pair_debug != 0) return 0;                     // the hooks make roles late on purpose
+    // only the waits a workgroup cannot recover from (band tokens, k_se_chunk's tile flag); a late speculative role
+    // of k_move_pair is benign -- role 0 draws the proposal itself, the traces are the same -- and only counted
     std::vector<uint32_t> late((size_t)s->cfg.B, 0u);
-    HIP_TRY(hipMemcpy(late.data(), s->ch.late, sizeof(uint32_t) * late.size(), hipMemcpyDeviceToHost));
+    uint32_t *fatal = s->ch.late + s->ch.late_fatal;
+    HIP_TRY(hipMemcpy(late.data(), fatal, sizeof(uint32_t) * late.size(), hipMemcpyDeviceToHost));
     for (size_t b = 0; b < late.size(); ++b)
-        if (late[b])
+        if (late[b]) {
+            // reported once: the draws read by THIS call are the unreliable ones, later bursts start clean
+            HIP_TRY(hipMemset(fatal, 0, sizeof(uint32_t) * late.size()));
             return fail(SEIR_ERR_STATE, "chain %d: %u in-launch hand-off(s) timed out -- draws since the last check are unreliable "
                         "(hmc_mode 2 / moves_mode 3 select the multi-launch forms)", (int)b, late[b]);
+        }
     return 0;
 }
 
@@ -1696,7 +1714,9 @@ extern "C" int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out) {
     if (rc) return rc;
     if (!out) return fail(SEIR_ERR_INVALID, "null pointer");
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-    HIP_TRY(hipMemcpy(out, s->ch.late, sizeof(uint32_t) * s->cfg.B, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> both((size_t)2 * s->cfg.B, 0u);
+    HIP_TRY(hipMemcpy(both.data(), s->ch.late, sizeof(uint32_t) * both.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < s->cfg.B; ++b) out[b] = both[b] + both[(size_t)s->cfg.B + b];
     return 0;
 }
 

@@ -281,9 +281,12 @@ int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, float *mean_ms
  * creation): the condition under which hmc_mode 0 runs the chunk roles inside the gradient launch. */
 int seir_sampler_xcd_local(seir_sampler *s);
 
-/* Number of k_move_pair launches per chain in which the authoritative workgroup gave up waiting for
- * the speculative one (it then re-draws the proposal itself: results are unaffected, throughput is
- * not).  out [B].  Should stay 0 outside the debug_pair test hooks. */
+/* Time-outs of waits inside a launch, per chain: out [B] = (a) k_move_pair launches in which the
+ * authoritative workgroup gave up waiting for a speculative one (it then draws the proposal itself:
+ * results are unaffected, throughput is not) + (b) waits that cannot be recovered from (band tokens,
+ * k_se_chunk's tile flag).  Only (b) makes the next seir_sampler_read_trace / seir_sampler_trace_wait
+ * fail (once: the counter is cleared when reported); (a) is benign and only counted here.  Both stay
+ * 0 outside the debug_pair test hooks. */
 int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out);
 
 /* ------------------------------------------------------------------------

@@ -33,15 +33,24 @@ def oracle_constants(cov, init):
 
 
 def build_case(name, seed=20210101, alpha_t_sd=0.0):
-    """name in synth.WORKLOADS or 'micro_MxT' -> dict(cov, events, init, u, k)."""
+    """name in synth.WORKLOADS, 'micro_MxT' or 'slow_MxT' -> dict(cov, events, init, u, k).
+
+    'slow_MxT': populations 40 times larger and a reproduction number just above one, so that the epidemic is
+    still running on the last day of a series of 400+ days (a 'micro' epidemic burns out after ~130 days and
+    would leave the day chunks beyond it -- the ones the long-series kernel forms exist for -- without events)."""
     if name in synth.WORKLOADS:
         cov = synth.make_covariates(name, seed)
+        params = None
     else:
+        kind = name.split("_")[0]
         M, T = (int(x) for x in name.split("_")[1].split("x"))
         cov = small_covariates(M, T, seed)
-    events, init, truth = synth.simulate_epidemic(
-        cov, seed, alpha_t_sd=alpha_t_sd,
-        params=None if name in synth.WORKLOADS else dict(alpha_0=-0.5))
+        params = dict(alpha_0=-0.5)
+        if kind == "slow":
+            import dataclasses
+            cov = dataclasses.replace(cov, N=cov.N * 40.0)
+            params = dict(alpha_0=-1.45)
+    events, init, truth = synth.simulate_epidemic(cov, seed, alpha_t_sd=alpha_t_sd, params=params)
     theta = synth.pack_params(truth, cov.M, cov.T)
     u = synth.unconstrain(theta)
     return dict(cov=cov, events=events, init=init, u=u, theta=theta,

@@ -124,10 +124,12 @@ def chi_square(idx, prob, min_expected=8.0):
 # ----------------------------------------------------------------------------------------------
 # exact-sample (joint) test
 # ----------------------------------------------------------------------------------------------
-def small_population_case(M=3, T=6, seed=5):
+def small_population_case(M=3, T=6, seed=5, gamma0=math.log(0.3), alpha_0=math.log(0.9)):
     """A few LADs with populations of a few hundred and a handful of infectives: event counts are
     small integers, where the feasibility bounds and the occult add/delete bookkeeping matter most.
-    Returns dict(cov, init, k, u, theta)."""
+    Returns dict(cov, init, k, u, theta).  With a removal rate of ~0.01/day and an infection rate just above it
+    (gamma0, alpha_0) the epidemic is a slow trickle of single events that is still going after 400 days: the
+    long-series forms of the kernels then see events in every day chunk."""
     rng = np.random.default_rng(seed)
     N = rng.integers(150, 400, size=M).astype(float)
     C = rng.integers(0, 12, size=(M, M)).astype(float)      # psi W colsum(C)/N < 1: the hazard stays positive
@@ -142,7 +144,7 @@ def small_population_case(M=3, T=6, seed=5):
     init = np.stack([N - E0 - I0, E0, I0, np.zeros(M)], axis=-1)
     k = so.make_constants(cov.C, cov.N, cov.W, cov.weekday, cov.area, cov.adjacency, init)
     theta = np.zeros(k.P)
-    theta[:6] = (0.5, 0.2, 0.1, math.log(0.3), 0.1, math.log(0.9))
+    theta[:6] = (0.5, 0.2, 0.1, gamma0, 0.1, alpha_0)
     theta[6:6 + T - 1] = rng.normal(0.0, 0.05, size=T - 1)
     theta[6 + T - 1:] = rng.normal(0.0, 0.5, size=M)
     y = theta[:2] - np.finfo(float).eps

@@ -96,6 +96,39 @@ def test_event_kernels_preserve_the_joint_distribution_of_simulated_epidemics(ap
     assert np.abs(z).max() < 4.5, (kernel, dict(zip(IL.STAT_NAMES, np.round(z, 2))))
 
 
+@pytest.mark.parametrize("moves", ["paired", "split"])
+@pytest.mark.parametrize("kernel", ("move/S->E", "move/E->I", "all"))
+def test_event_kernels_preserve_the_joint_distribution_over_a_long_series(api, kernel, moves):
+    """The same joint test on 3 LADs x 400 days, where the series is longer than the 384 days the wave-level
+    proposals cover and the block form (k_move_pair<false> / k_move_pa2<false>) runs: a slow trickle of single
+    events that is still going on the last day, updates that reach across the day-chunk boundaries (dmax = 84),
+    the occult window [379, 400) straddling day 384."""
+    SeirModel, ChainSampler = api
+    case = IL.small_population_case(M=3, T=400, seed=5, gamma0=math.log(0.012), alpha_0=math.log(0.02))
+    k, th = case["k"], case["theta"]
+    M, T = k.M, k.T
+    cfg = dict(dmax=84, nmax=5, m=2, occult_nmax=4, num_event_time_updates=3)
+    B, sweeps = 4096, 4
+    par = np.tile(th[:5], (B, 1))
+    a = th[5] + np.concatenate([[0.0], np.cumsum(th[6:6 + T - 1])])
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        ev0 = model.simulate(par, np.tile(a, (B, 1)), np.tile(th[6 + T - 1:], (B, 1)), k.W, k.weekday_c,
+                             np.tile(case["init"], (B, 1, 1)), seed=78)
+        with ChainSampler(model, cfg, B, seed=32, trace_capacity=1, record_events=False,
+                          disable=IL.only(kernel), moves=moves) as s:
+            s.set_state(np.tile(case["u"], (B, 1)), ev0)
+            s.run(sweeps)
+            _, ev1, _ = s.get_state()
+    assert (ev0[:, :, 384:, :2].sum(axis=(1, 2, 3)) > 0).mean() > 0.9, "the epidemics must reach the last day chunk"
+    assert np.array_equal(ev1[..., 2], ev0[..., 2]), "the observed I->R events must never move"
+    changed = ev1 != ev0
+    assert changed.any(axis=(1, 2, 3)).mean() > 0.3
+    assert changed[:, :, 384:].any() and changed[:, :, :64].any()
+    s0, s1 = IL.event_statistics(ev0, case["init"]), IL.event_statistics(ev1, case["init"])
+    z = IL.paired_z(s0, s1)
+    assert np.abs(z).max() < 4.5, (kernel, dict(zip(IL.STAT_NAMES, np.round(z, 2))))
+
+
 @pytest.mark.parametrize("hmc", ["chunk", "single"])
 def test_hmc_recovers_the_prior_when_the_likelihood_is_flat(api, hmc):
     """No infectives, no events: the HMC update targets the prior of model_spec.py:140-198 through the

@@ -343,3 +343,21 @@ def test_one_launch_and_three_launch_evaluations_give_the_same_bits(Model, name,
     for key in (("fused", 0), ("fused", 2)):
         for (a, b, c), (x, y, z) in zip(ref, res[key]):
             assert np.array_equal(a, x) and np.array_equal(b, y) and np.array_equal(c, z), key
+
+
+def test_one_context_serves_batches_of_different_sizes(Model):
+    """The one-launch form keeps a counter pair per chain and one running target per context: after a batch of 8 the
+    chains 8..15 of a batch of 16 must not be left one launch behind the target (they would time out and evaluate
+    without their producers' data).  8, 16, 8, 16 and a partial batch on ONE context, each against a context of its
+    own size, bit for bit, and no hand-off time-out."""
+    case = H.build_case("uk380", 25, alpha_t_sd=0.005)
+    u, ev = _batch(case, 16, 25)
+    ref = {}
+    for B in (8, 16, 5):
+        with Model(case["cov"], case["init"], max_chains=B) as model:
+            ref[B] = model.log_prob_grad(u[:B], ev[:B])
+    with Model(case["cov"], case["init"], max_chains=16) as model:
+        for B in (8, 16, 8, 5, 16, 16):
+            lp, g = model.log_prob_grad(u[:B], ev[:B])        # raises on a hand-off time-out
+            assert np.array_equal(lp, ref[B][0]) and np.array_equal(g, ref[B][1]), B
+            assert np.array_equal(model.log_prob(u[:B], ev[:B]), ref[B][0]), B

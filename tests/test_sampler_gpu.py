@@ -123,6 +123,86 @@ def test_move_configurations_match_oracle(api, name, cfg, eps):
     _compare(tr, oracles, n, B, cfg)
 
 
+_ORACLE_CACHE = {}
+
+
+@pytest.mark.parametrize("moves", ["paired", "split", "paired-nopre", "paired+single"])
+@pytest.mark.parametrize("name,cfg,seed,eps,n", [
+    # T > 384: the block form of the proposals (k_move_pair<false> / k_move_pa2<false>), one row and many
+    ("slow_3x400", CFG_REF, 11, 3e-5, 5),
+    ("slow_70x400", CFG_SMALL, 12, 3e-5, 3),
+    # T > 512: two day passes of the single-workgroup HMC kernels (k_hmc_step<*, 2, *>), 9 day chunks (rolled chunk loops)
+    ("slow_5x520", CFG_REF, 13, 3e-5, 5),
+    # M > 512: two row passes (k_hmc_step<*, *, 2>), the M-chunks no longer sum the row partials themselves
+    ("slow_520x70", CFG_SMALL, 14, 3e-5, 3),
+    # both, and 12 day chunks as at SYN-2048 x 730
+    ("slow_530x730", CFG_REF, 15, 3e-6, 2),
+])
+def test_long_series_and_wide_kernel_forms_match_oracle(api, name, cfg, seed, eps, n, moves):
+    """Everything BASELINE's largest configuration (SYN-2048 x 730) runs and the smaller cases do not: the block
+    form of the event-update proposals (series longer than 384 days) and the multi-pass instances of the
+    single-workgroup HMC kernels (T > 512, M > 512), draw by draw against the oracle in every launch form.  The
+    'slow' epidemics are still running on the last day, so every day chunk holds events."""
+    form = dict(moves=moves.split("+")[0], hmc="single" if moves.endswith("+single") else "chunk")
+    SeirModel, ChainSampler = api
+    case = H.build_case(name, seed, alpha_t_sd=0.005)
+    B = 2
+    u, ev = _start(case, B, seed, scale=0.01)
+    T = case["k"].T
+    assert case["events"][:, T - 16:, :2].sum() > 0 and case["events"][:, 384:, :2].sum() > 0 or T < 384
+    if name not in _ORACLE_CACHE:                       # the same oracle trace serves the four launch forms
+        oracles = []
+        for b in range(B):
+            ch = mo.OracleChain(case["k"], cfg, u[b], ev[b], seed=77, chain_id=5 + b)
+            ch.eps = eps
+            oracles.append([ch.sweep_once() for _ in range(n)])
+        _ORACLE_CACHE[name] = oracles
+    oracles = _ORACLE_CACHE[name]
+    with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+        with ChainSampler(model, cfg, B, seed=77, first_chain_id=5, trace_capacity=n, **form) as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=eps)
+            tr = s.sample(n)
+            _compare(tr, oracles, n, B, cfg)
+            assert tr.hmc["is_accepted"].any()
+            assert any(tr.moves[k]["is_accepted"].any() for k in tr.moves)
+    if T > 384:
+        # the proposals did reach the days beyond the wave form's range
+        days = np.concatenate([tr.moves[k]["proposed_delta"][..., 1, :].ravel() for k in tr.moves])
+        assert (days >= 384).any()
+
+
+def test_sampler_matches_oracle_draw_by_draw_at_uk380(api):
+    """The headline size against the oracle sampler itself (not only launch-form equivalence): three sweeps of two
+    chains, the oracle with the C restatement of the density (full re-evaluation for every proposal, as the
+    reference does: mcmc_kernel_factory.py:72-83).  Covers what the micro cases cannot: six-word ballot masks over
+    380 rows, six-register rows over 365 days, 24 band workgroups."""
+    from oracle import c_binding
+    SeirModel, ChainSampler = api
+    case = H.build_case("uk380", 6)
+    k = case["k"]
+    B, n, eps = 2, 3, 1.5e-5
+    u, ev = _start(case, B, 6, scale=0.002)
+    oracles = []
+    for b in range(B):
+        ch = mo.OracleChain(k, CFG_REF, u[b], ev[b], seed=21, chain_id=3 + b,
+                            log_prob_fn=lambda u_, e_: c_binding.evaluate(k, u_, e_, 1),
+                            log_prob_grad_fn=lambda u_, e_: c_binding.evaluate(k, u_, e_, 1, want_grad=True))
+        ch.eps = eps
+        oracles.append([ch.sweep_once() for _ in range(n)])
+    for moves in ("paired", "split"):
+        with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+            with ChainSampler(model, CFG_REF, B, seed=21, first_chain_id=3, trace_capacity=n, moves=moves) as s:
+                s.set_state(u, ev)
+                s.set_kernel(step_size=eps)
+                tr = s.sample(n)
+        _compare(tr, oracles, n, B, CFG_REF)
+        rows = np.concatenate([tr.moves[key]["proposed_delta"][..., 0, :].ravel() for key in tr.moves])
+        assert (rows >= 64).any() and (rows >= 320).any()
+    assert tr.hmc["is_accepted"].any()
+    assert any(tr.moves[key]["is_accepted"].any() for key in tr.moves)
+
+
 def test_adaptation_windows_match_oracle(api):
     """Dual averaging, then dual averaging + diagonal mass adaptation (the fast and slow
     windows of inference.py:60-196), compared step by step.  Each window restarts from the
