@@ -108,6 +108,71 @@ __device__ __forceinline__ void l1me_inv(double r, double &L, double &inv, const
         inv = e / om;
     }
 }
+// The same pair with the literals of the common path in SCALAR registers.  A Horner step fma(x, p, c) with a literal c
+// compiles to two v_mov_b32 (the literal into the accumulator's registers) + v_fmac_f64: three vector instructions where
+// one v_fma_f64 with c as its scalar operand would do -- 34 of the ~62 vector instructions of a cell of the S->E term.
+// In a kernel that streams its cells from memory that is hidden behind the loads (k_se: 7.0 us either way); the
+// persistent leapfrog kernel keeps its cells in registers and is bound by exactly this instruction count.  SeK::load()
+// makes the constants by s_mov_b32 (scalar ALU, its own issue port) through inline asm, so that the compiler sees
+// run-time scalars and uses them as the one constant-bus operand a VOP3 instruction may have.  Same operations in the
+// same order as l1me_inv / fast_log: bit-identical results.
+template <unsigned long long BITS>
+__device__ __forceinline__ double sgpr_literal() {
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "i"((unsigned)(BITS & 0xffffffffull)));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "i"((unsigned)(BITS >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+#define SEIR_SK(x) sgpr_literal<__builtin_bit_cast(unsigned long long, (double)(x))>()
+struct SeK {
+    double g1, g2, g3, g4, g5, g6, g7, ln2hi, ln2lo;       // fast_log
+    double l1, l2, l3, l4, i1, i2, i3, i4, mhalf;          // the two series
+    __device__ __forceinline__ void load() {
+        g1 = SEIR_SK(-0.125); g2 = SEIR_SK(0.14285714285714285); g3 = SEIR_SK(-0.16666666666666666); g4 = SEIR_SK(0.2);
+        g5 = SEIR_SK(-0.25); g6 = SEIR_SK(0.33333333333333331); g7 = SEIR_SK(-0.5);
+        ln2hi = SEIR_SK(0.69314718055994529); ln2lo = SEIR_SK(2.3190468138462996e-17);
+        l1 = SEIR_SK(4.1666666666666664e-2); l2 = SEIR_SK(3.4722222222222224e-4); l3 = SEIR_SK(5.5114638447971785e-6);
+        l4 = SEIR_SK(1.0333994708994709e-7);
+        i1 = SEIR_SK(8.3333333333333329e-2); i2 = SEIR_SK(1.3888888888888889e-3); i3 = SEIR_SK(3.3068783068783071e-5);
+        i4 = SEIR_SK(8.2671957671957672e-7);
+        mhalf = SEIR_SK(-0.5);
+    }
+};
+__device__ __forceinline__ double fast_log_k(double x, const double2 *tab, const SeK &k) {
+    const long long bits = __double_as_longlong(x);
+    const int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    const int i = (int)((bits >> 45) & 127);
+    const double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    const double2 tc = tab[i];
+    const double f = fma(m, tc.x, -1.0);
+    double p = fma(f, k.g1, k.g2);
+    p = fma(f, p, k.g3);
+    p = fma(f, p, k.g4);
+    p = fma(f, p, k.g5);
+    p = fma(f, p, k.g6);
+    p = fma(f, p, k.g7);
+    p = fma(f * f, p, f);
+    const double kd = (double)e;
+    return fma(kd, k.ln2hi, tc.y) + fma(kd, k.ln2lo, p);
+}
+// the series alone (callers redo the rare arguments outside [L1ME_SERIES_MIN, L1ME_SERIES_MAX] with l1me_inv): no branch,
+// so the cells of a lane can be interleaved -- a dependent fp64 operation has ~32 cycles of latency against 4 of issue
+__device__ __forceinline__ void l1me_inv_series_k(double r, double &L, double &inv, const double2 *tab, const SeK &k) {
+    const double r2 = r * r, ri = fast_rcp(r);
+    L = fast_log_k(r, tab, k) + r * (k.mhalf + r * (k.l1 - r2 * (k.l2 - r2 * (k.l3 - r2 * k.l4))));
+    inv = ri - 0.5 + r * (k.i1 - r2 * (k.i2 - r2 * (k.i3 - r2 * k.i4)));
+}
+__device__ __forceinline__ void l1me_inv_k(double r, double &L, double &inv, const double2 *tab, const SeK &k) {
+    if (r >= L1ME_SERIES_MIN && r <= L1ME_SERIES_MAX) {
+        const double r2 = r * r, ri = fast_rcp(r);
+        L = fast_log_k(r, tab, k) + r * (k.mhalf + r * (k.l1 - r2 * (k.l2 - r2 * (k.l3 - r2 * k.l4))));
+        inv = ri - 0.5 + r * (k.i1 - r2 * (k.i2 - r2 * (k.i3 - r2 * k.i4)));
+    } else {
+        const double e = exp(-r), om = 1.0 - e;
+        L = log(om);
+        inv = e / om;
+    }
+}
 // The series branch alone, for callers that sort out the rare lanes outside [L1ME_SERIES_MIN, L1ME_SERIES_MAX]
 // themselves (the contraction's epilogue: branch-free cells can be interleaved, and the libm branch costs ~40
 // registers wherever it is inlined)

@@ -640,6 +640,32 @@ inline bool xcd_affinity_applies(int per, int nb) {
     return (nb == 1 || nb == 2 || nb == 4 || (nb > 0 && nb % 8 == 0)) && ((long long)per * nb) % 8 == 0;
 }
 
+// The S->E cells of one lane (NR rows, one day): rate r = (exp(a_t) exp(b_m)/N_m (I + psi W_t F) + floor) dt, L = log(1 - e^-r),
+// inv = 1/expm1(r).  All NR cells go through the branch-free series with its literals in scalar registers (device_math.h:
+// SeK) -- straight-line code, so the compiler interleaves the cells' dependent fp64 chains (~32 cycles of latency against 4 of
+// issue) -- and a cell whose rate is outside the series' range (rare: daily hazards are 1e-5..1e-2) is redone by the full
+// l1me_inv in a cold block.  One definition for every kernel that evaluates the term (k_se, k_se_chunk, k_leap): the
+// sampler's launch forms must give the same bits.
+template <int NR>
+__device__ __forceinline__ void se_cells(double ea_t, const double (&eb)[NR], const double (&I)[NR], double psiW, const double (&F)[NR],
+                                         double rate_floor, double dt, const double2 *ltab, const SeK &sk,
+                                         double (&ee)[NR], double (&lam0)[NR], double (&rr)[NR], double (&L)[NR], double (&inv)[NR]) {
+    bool odd = false;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        ee[r] = ea_t * eb[r];
+        lam0[r] = ee[r] * (I[r] + psiW * F[r]);
+        rr[r] = (lam0[r] + rate_floor) * dt;
+        l1me_inv_series_k(rr[r], L[r], inv[r], ltab, sk);
+        odd = odd || !(rr[r] >= L1ME_SERIES_MIN && rr[r] <= L1ME_SERIES_MAX);
+    }
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (!(rr[r] >= L1ME_SERIES_MIN && rr[r] <= L1ME_SERIES_MAX)) l1me_inv(rr[r], L[r], inv[r], ltab);
+    }
+}
+
 // TSM (sampler, GRAD, SRC 1): tile scalars for the chunked leapfrog -- 0 none, 1 column scalars,
 // 2 column and row scalars (Work::TS); compile-time so that the plain kernel carries none of it.
 template <bool GRAD, int SRC, int TSM>
@@ -695,25 +721,25 @@ __device__ __forceinline__ void se_tile(const Dims &d, const Consts &c, const Wo
     __syncthreads();
     double ll = 0.0, gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0;
     double *myrow = rowbuf + (GRAD ? wave * SE_RW * SE_RS : 0);
+    // the wave's SE_RW cells side by side: rates, log(1 - e^-r) and 1/expm1(r) by the branch-free series (se_cells), then the sums
+    SeK sk;
+    sk.load();
+    double ee[SE_RW], lam0[SE_RW], rr[SE_RW], L[SE_RW], inv[SE_RW];
+    se_cells<SE_RW>(ea_t, eb, I, psiW, F, d.rate_floor, d.dt, ltab, sk, ee, lam0, rr, L, inv);
 #pragma unroll
     for (int r = 0; r < SE_RW; ++r) {
-        const double ee = ea_t * eb[r];
-        const double lam0 = ee * (I[r] + psiW * F[r]);
-        const double rr = (lam0 + d.rate_floor) * d.dt;
-        double L, inv;
-        l1me_inv(rr, L, inv, ltab);
         const bool has = kse[r] != 0.0;
-        ll += (has ? kse[r] * L : 0.0) - snk[r] * rr;
+        ll += (has ? kse[r] * L[r] : 0.0) - snk[r] * rr[r];
         if (GRAD) {
-            const double gl = d.dt * ((has ? kse[r] * inv : 0.0) - snk[r]);
-            const double ge = gl * lam0;
+            const double gl = d.dt * ((has ? kse[r] * inv[r] : 0.0) - snk[r]);
+            const double ge = gl * lam0[r];
             myrow[r * SE_RS + lane] = ge;
             colacc += ge;
             if (ts_rows) {                                // uniform
                 rlacc = fma(ge, ts_l[r], rlacc);          // sum_m l_m (row sum)_m and sum_m s_m (row sum)_m, cell by cell
                 rsacc = fma(ge, ts_s[r], rsacc);
             }
-            gpsi += gl * ee * Wt * F[r];
+            gpsi += gl * ee[r] * Wt * F[r];
         }
     }
     llbuf[wave][lane] = ll;

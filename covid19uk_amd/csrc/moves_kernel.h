@@ -43,20 +43,6 @@ struct MvShared {
     int pend_valid[MMAX];
 };
 
-// exclusive prefix over the block (thread order); sh [MVW]
-__device__ __forceinline__ int mv_excl_scan(int v, int *sh, int &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int inc = wave_incl_scan(v, lane);
-    lds_barrier();
-    if (lane == 63) sh[wave] = inc;
-    lds_barrier();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int j = 0; j < MVW; ++j) { const int x = sh[j]; tot += x; if (j < wave) base += x; }
-    total = tot;
-    return base + inc - v;
-}
-
 // min over the 64 lanes (result uniform): row_shr 1,2,4,8, row_bcast 15/31; min is idempotent, so
 // the overlapping Hillis-Steele windows are harmless.  Lanes without a source receive INT_MAX.
 template <int CTRL, int ROW_MASK>
@@ -71,26 +57,6 @@ __device__ __forceinline__ int wave_min_int(int v) {
     v = dpp_min_step<0x142, 0xa>(v);
     v = dpp_min_step<0x143, 0xc>(v);
     return __builtin_amdgcn_readlane(v, 63);
-}
-
-template <int NV>
-__device__ __forceinline__ void mv_minv(int (&v)[NV], int *sh) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = wave_min_int(v[k]);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    lds_barrier();
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) sh[wave * NV + k] = v[k];
-    }
-    lds_barrier();
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        int x = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < MVW; ++j) x = min(x, sh[j * NV + k]);
-        v[k] = x;
-    }
 }
 
 __device__ __forceinline__ void mv_sum2(double &a, double &b2, double *sh) {
@@ -109,7 +75,6 @@ __device__ __forceinline__ void mv_sum2(double &a, double &b2, double *sh) {
 struct MvLds {
     const int *rt;         // [M] row totals of the target transition's events (LDS copy, patched)
     int *rg;               // [M] events of the target transition inside the occult range (LDS)
-    int *rk, *rsrc, *rdst; // [MMAX][T+1] staged rows (LDS): target events, compartments either side at start of day
 #ifdef SEIR_STAMPS
     double *stamp_hs; bool stamp_on;
 #endif
@@ -477,292 +442,15 @@ __device__ inline void mv_propose_wave(const Dims &d, const Work &w, const Sampl
 
 // rows_only: stop after the rows are chosen (sm.nsel, sm.sel[j] = row): what a proposal's rows are
 // depends on the row totals and the uniforms only.
-// WF (compile time, chosen by the host from Tp <= 384): the wave form above; the kernels are instantiated for one form
-// each, so that an instance carries the code of that form only.
-template <bool WF>
-__device__ inline void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
-                                  MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab,
-                                  bool rows_only = false) {
-    if (WF) {                                                // up to 384 days: a row is six registers per lane
-        mv_propose_wave<6>(d, w, s, ch, b, spec, sm, L, ltab, rows_only);
-        return;
-    }
-    Move &mv = sm.mv;
-    const int tid = threadIdx.x, M = d.M, T = d.T, T1 = T + 1;
-#ifdef SEIR_STAMPS
-    double *stamp_hs = L.stamp_hs; const bool stamp_on = L.stamp_on;
-#endif
-    MSTAMP(4);
-    const int tgt = spec.tgt;
-    const int per = (M + MVB - 1) / MVB;
-    const int r_lo = tid * per, r_hi = min(M, r_lo + per);
-
-    if (spec.kind == 0) {
-        // ---- UncalibratedEventTimesUpdate ---------------------------------
-        const int *rt = L.rt;
-        int c = 0;
-        for (int m = r_lo; m < r_hi; ++m) c += rt[m] > 0 ? 1 : 0;
-        int H;
-        const int before = mv_excl_scan(c, sm.ired, H);          // also publishes sm.u / mv init
-        const int nsel = min(min(s.mmax, MMAX), H);
-        // positions of the nsel distinct hot rows (every thread computes the same values)
-        int pos[MMAX], chosen[MMAX];
-        for (int j = 0; j < nsel; ++j) {
-            int p = rng_index(sm.u[2 * j][0], H - j);
-            for (int a = 0; a < j; ++a)
-                if (p >= chosen[a]) ++p;
-            int ins = j;
-            while (ins > 0 && chosen[ins - 1] > p) { chosen[ins] = chosen[ins - 1]; --ins; }
-            chosen[ins] = p;
-            pos[j] = p;
-        }
-        for (int j = 0; j < nsel; ++j)
-            if (pos[j] >= before && pos[j] < before + c) {
-                int k = pos[j] - before;
-                for (int m = r_lo; m < r_hi; ++m)
-                    if (rt[m] > 0) {
-                        if (k == 0) { sm.sel[j] = m; break; }
-                        --k;
-                    }
-            }
-        if (tid == 0) sm.nsel = nsel;
-        lds_barrier();
-        if (rows_only) return;
-        MSTAMP(5);
-        // stage the chosen rows: k[t], source and destination compartments at the start of day t in [0,T]
-        {
-            constexpr int NST = 4;                                // elements per thread per batch
-            for (int base = tid; base < nsel * T1; base += MVB * NST) {
-                int vk[NST], vs[NST], vd[NST];
-#pragma unroll
-                for (int q = 0; q < NST; ++q) {
-                    const int idx = base + q * MVB;
-                    vk[q] = vs[q] = vd[q] = 0;
-                    if (idx < nsel * T1) {
-                        const int j = idx / T1, t = idx - j * T1;
-                        const size_t rowoff = ((size_t)b * d.Mp + sm.sel[j]) * d.Tp;
-                        vk[q] = t < T ? w.K[tgt][rowoff + t] : 0;
-                        vs[q] = comp_start(d, w, rowoff, tgt, t);
-                        vd[q] = comp_start(d, w, rowoff, tgt + 1, t);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NST; ++q) {
-                    const int idx = base + q * MVB;
-                    if (idx < nsel * T1) { L.rk[idx] = vk[q]; L.rsrc[idx] = vs[q]; L.rdst[idx] = vd[q]; }
-                }
-            }
-        }
-        __syncthreads();
-        MSTAMP(6);
-        // day of each row: the floor(u D)-th day with events
-        const int tper = (T + MVB - 1) / MVB;
-        const int t_lo = tid * tper, t_hi = min(T, t_lo + tper);
-        int Dj[MMAX], tj[MMAX];
-        // two rows per scan: the counts (<= T <= 1024) travel in the two halves of one int
-        for (int j0 = 0; j0 < nsel; j0 += 2) {
-            const bool two = j0 + 1 < nsel;
-            const int *k0 = L.rk + j0 * T1, *k1 = L.rk + (two ? j0 + 1 : j0) * T1;
-            int c0 = 0, c1 = 0;
-            for (int t = t_lo; t < t_hi; ++t) { c0 += k0[t] > 0 ? 1 : 0; c1 += (two && k1[t] > 0) ? 1 : 0; }
-            int Dp;
-            const int befp = mv_excl_scan(c0 | (c1 << 16), sm.ired, Dp);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 1 && !two) break;
-                const int j = j0 + h;
-                const int *kr = h ? k1 : k0;
-                const int cc = h ? c1 : c0, bef = h ? (befp >> 16) : (befp & 0xffff), D = h ? (Dp >> 16) : (Dp & 0xffff);
-                const int r = rng_index(sm.u[2 * j][1], D);
-                if (r >= bef && r < bef + cc) {
-                    int k = r - bef;
-                    for (int t = t_lo; t < t_hi; ++t)
-                        if (kr[t] > 0) {
-                            if (k == 0) { sm.sel[j] = (sm.sel[j] & 0xffff) | (t << 16); break; }
-                            --k;
-                        }
-                }
-                Dj[j] = D;
-            }
-        }
-        lds_barrier();
-        MSTAMP(7);
-        // bounds: min over (lo,hi] of the compartment that loses x, and of the one that gains it
-        int mins[2 * MMAX];
-        int mj[MMAX], dj[MMAX], t2j[MMAX];
-#pragma unroll
-        for (int j = 0; j < MMAX; ++j) {
-            mins[2 * j] = mins[2 * j + 1] = 0x7fffffff;
-            if (j >= nsel) continue;
-            mj[j] = sm.sel[j] & 0xffff; tj[j] = sm.sel[j] >> 16;
-            const int v = rng_index(sm.u[2 * j + 1][0], 2 * s.dmax);
-            dj[j] = v < s.dmax ? v - s.dmax : v - s.dmax + 1;
-            t2j[j] = tj[j] + dj[j];
-            if (t2j[j] < 0 || t2j[j] >= T) continue;             // out of range: rejected below
-            const int lo = min(tj[j], t2j[j]), hi = max(tj[j], t2j[j]);
-            const bool later = dj[j] > 0;
-            const int *decp = (later ? L.rdst : L.rsrc) + j * T1, *incp = (later ? L.rsrc : L.rdst) + j * T1;
-            for (int tau = lo + 1 + tid; tau <= hi; tau += MVB) {
-                mins[2 * j] = min(mins[2 * j], decp[tau]);
-                mins[2 * j + 1] = min(mins[2 * j + 1], incp[tau]);
-            }
-        }
-        mv_minv<2 * MMAX>(mins, sm.ired);
-        MSTAMP(8);
-        // one lane per metapopulation finishes its update
-        const int jj = tid >> 6;
-        if ((tid & 63) == 0 && jj < nsel) {
-            const int j = jj, m = mj[j], t = tj[j], delta = dj[j], t2 = t2j[j];
-            if (t2 < 0 || t2 >= T) {
-                sm.pend_valid[j] = 0;
-                mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = 0;
-                sm.logq_part[j] = 0.0;
-            } else {
-                const bool later = delta > 0;
-                const bool dec_unbounded = !later && tgt == 0;   // S: prev_event_id None -> no bound
-                const bool inc_unbounded = later && tgt == 0;
-                const int min_dec = dec_unbounded ? 0x7fffffff : mins[2 * j];
-                const int min_inc = mins[2 * j + 1];
-                const int *kr = L.rk + j * T1;
-                const int kt = kr[t], kt2 = kr[t2], D = Dj[j];
-                const int xmax = max(0, min(min(s.nmax, kt), min_dec));
-                const int x = rng_index(sm.u[2 * j + 1][1], xmax + 1);
-                const int Dn = D - ((x > 0 && x == kt) ? 1 : 0) + ((x > 0 && kt2 == 0) ? 1 : 0);
-                const long long binc = inc_unbounded ? 0x7fffffffLL : (long long)min_inc + x;
-                const int xmax_r = (int)max(0LL, min((long long)min(s.nmax, kt2 + x), binc));
-                // a null sub-move (x == 0) is its own reverse: no correction (see oracle/mcmc_oracle.py,
-                // event_time_move, and tests/test_invariance*.py)
-                sm.logq_part[j] = x > 0 ? (-mv_log((double)Dn, ltab) - mv_log((double)(xmax_r + 1), ltab)) -
-                                              (-mv_log((double)D, ltab) - mv_log((double)(xmax + 1), ltab))
-                                        : 0.0;
-                sm.pend_valid[j] = 1;
-                mv.m[j] = m; mv.a[j] = t; mv.b[j] = t2; mv.dka[j] = -x; mv.dkb[j] = x;
-                mv.lo[j] = min(t, t2); mv.hi[j] = max(t, t2);
-                mv.dsrc[j] = later ? x : -x;
-                mv.tm[j] = m; mv.tt[j] = t; mv.tdt[j] = delta; mv.tx[j] = x;
-            }
-        }
-        lds_barrier();
-        MSTAMP(9);
-        if (tid == 0) {
-            // compact the in-range updates (order preserved) and combine the correction
-            int n = 0;
-            double lq = 0.0;
-            for (int j = 0; j < nsel; ++j) {
-                if (sm.pend_valid[j] == 0) { mv.valid = 0; continue; }
-                lq += sm.logq_part[j];
-                if (n != j) {
-                    mv.m[n] = mv.m[j]; mv.a[n] = mv.a[j]; mv.b[n] = mv.b[j]; mv.dka[n] = mv.dka[j];
-                    mv.dkb[n] = mv.dkb[j]; mv.lo[n] = mv.lo[j]; mv.hi[n] = mv.hi[j]; mv.dsrc[n] = mv.dsrc[j];
-                }
-                mv.LO = min(mv.LO, mv.lo[n]); mv.HI = max(mv.HI, mv.hi[n]);
-                if (tgt == 1 && mv.dsrc[n] != 0) mv.any_dI = 1;
-                ++n;
-            }
-            mv.n = n;
-            mv.logq = lq;
-        }
-    } else {
-        // ---- UncalibratedOccultUpdate --------------------------------------
-        const int R = s.tr_hi - s.tr_lo;
-        const int *rg = L.rg;
-        int c = 0;
-        for (int m = r_lo; m < r_hi; ++m) c += rg[m] > 0 ? 1 : 0;
-        int Hd;
-        const int before = mv_excl_scan(c, sm.ired, Hd);
-        const double u_br = sm.u[0][0], u_m = sm.u[0][1], u_t = sm.u[1][0], u_x = sm.u[1][1];
-        const bool is_del = (u_br < 0.5) && Hd > 0;
-        if (!is_del) {
-            if (tid == 0) sm.sel[0] = rng_index(u_m, M);
-        } else {
-            const int r = rng_index(u_m, Hd);
-            if (r >= before && r < before + c) {
-                int k = r - before;
-                for (int m = r_lo; m < r_hi; ++m)
-                    if (rg[m] > 0) {
-                        if (k == 0) { sm.sel[0] = m; break; }
-                        --k;
-                    }
-            }
-        }
-        if (tid == 0) sm.nsel = 1;
-        lds_barrier();
-        if (rows_only) return;
-        MSTAMP(5);
-        const int m = sm.sel[0];
-        const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
-        for (int t = tid; t < T1; t += MVB) {
-            L.rk[t] = t < T ? w.K[tgt][rowoff + t] : 0;
-            L.rsrc[t] = comp_start(d, w, rowoff, tgt, t);
-            L.rdst[t] = comp_start(d, w, rowoff, tgt + 1, t);
-        }
-        __syncthreads();
-        MSTAMP(6);
-        // hot days of row m inside the range; the day of a delete is the floor(u Dm)-th of them
-        int cc = 0;
-        const int rper = (R + MVB - 1) / MVB;
-        const int i_lo = tid * rper, i_hi = min(R, i_lo + rper);
-        for (int i = i_lo; i < i_hi; ++i) cc += L.rk[s.tr_lo + i] > 0 ? 1 : 0;
-        int Dm;
-        const int bef = mv_excl_scan(cc, sm.ired, Dm);
-        if (is_del) {
-            const int r = rng_index(u_t, Dm);
-            if (r >= bef && r < bef + cc) {
-                int k = r - bef;
-                for (int i = i_lo; i < i_hi; ++i)
-                    if (L.rk[s.tr_lo + i] > 0) {
-                        if (k == 0) { sm.sel[1] = s.tr_lo + i; break; }
-                        --k;
-                    }
-            }
-        } else if (tid == 0) {
-            sm.sel[1] = s.tr_lo + rng_index(u_t, R);
-        }
-        lds_barrier();
-        MSTAMP(7);
-        const int t = sm.sel[1];
-        int mins[2] = {0x7fffffff, 0x7fffffff};
-        for (int tau = t + 1 + tid; tau <= T; tau += MVB) { mins[0] = min(mins[0], L.rsrc[tau]); mins[1] = min(mins[1], L.rdst[tau]); }
-        mv_minv<2>(mins, sm.ired);
-        MSTAMP(8);
-        if (tid == 0) {
-            const int min_src = tgt == 0 ? 0x7fffffff : mins[0], min_dst = mins[1];
-            const int kt = L.rk[t], rt_m = rg[m];
-            const double lM = mv_log((double)M, ltab), lR = mv_log((double)R, ltab), l2 = 0.6931471805599453;
-            int x;
-            if (!is_del) {
-                const int xmax = max(0, min(s.occult_nmax, min_src));
-                x = rng_index(u_x, xmax + 1);
-                const double qf = (Hd > 0 ? -l2 : 0.0) - lM - lR - mv_log((double)(xmax + 1), ltab);
-                const int Hd2 = Hd + ((rt_m == 0 && x > 0) ? 1 : 0);
-                const int Dm2 = Dm + ((kt == 0 && x > 0) ? 1 : 0);
-                const long long bd = (long long)min_dst + x;
-                const int xmax_r = (int)max(0LL, min((long long)min(s.occult_nmax, kt + x), bd));
-                const double qr = (Hd2 > 0 && kt + x > 0)
-                                      ? -l2 - mv_log((double)Hd2, ltab) - mv_log((double)Dm2, ltab) - mv_log((double)(xmax_r + 1), ltab)
-                                      : -INFINITY;
-                mv.logq = qr - qf;
-                mv.dka[0] = x; mv.dsrc[0] = -x;
-            } else {
-                const int xmax = max(0, min(min(s.occult_nmax, kt), min_dst));
-                x = rng_index(u_x, xmax + 1);
-                const double qf = -l2 - mv_log((double)Hd, ltab) - mv_log((double)Dm, ltab) - mv_log((double)(xmax + 1), ltab);
-                const int Hd2 = Hd - ((x > 0 && rt_m == x) ? 1 : 0);
-                const long long bs = tgt == 0 ? 0x7fffffffLL : (long long)min_src + x;
-                const int xmax_r = (int)max(0LL, min((long long)s.occult_nmax, bs));
-                const double qr = (Hd2 > 0 ? -l2 : 0.0) - lM - lR - mv_log((double)(xmax_r + 1), ltab);
-                mv.logq = qr - qf;
-                mv.dka[0] = -x; mv.dsrc[0] = x;
-            }
-            mv.n = 1;
-            mv.m[0] = m; mv.a[0] = t; mv.b[0] = -1; mv.dkb[0] = 0;
-            mv.lo[0] = t; mv.hi[0] = T - 1;
-            mv.LO = t; mv.HI = T - 1;
-            mv.any_dI = (tgt == 1 && x != 0) ? 1 : 0;
-            mv.tm[0] = m; mv.tt[0] = t; mv.tdt[0] = is_del ? -1 : 1; mv.tx[0] = x;
-        }
-    }
-    lds_barrier();
+// NCH (compile time, chosen by the host from ceil64(T)): 64-day chunks a row is held in -- 6 (T <= 384: UK-380, NI-11),
+// 12 (T <= 768: SYN-2048 x 730) or 16 (T <= 1024, the sampler's limit); the kernels are instantiated per value, so that
+// an instance carries one size's code.  (Rounds 1-2 had a block-level form for T > 384 -- scans through LDS, ten
+// workgroup barriers; the wave form replaced it at every size in round 3.)
+template <int NCH>
+__device__ __forceinline__ void mv_propose(const Dims &d, const Work &w, const SamplerCfg &s, const Chains &ch, int b,
+                                           MoveSpec spec, MvShared &sm, const MvLds &L, const double2 *ltab,
+                                           bool rows_only = false) {
+    mv_propose_wave<NCH>(d, w, s, ch, b, spec, sm, L, ltab, rows_only);
 }
 
 // events of the target transition inside the occult range, for every row, into LDS (M beyond the prefetch width)
@@ -778,10 +466,10 @@ __device__ __forceinline__ void range_totals_to_lds(const Dims &d, const Work &w
 // grid (nrb_d, B), MVB threads.  The pending descriptor is read from buffer pbuf, the next one
 // written to pbuf^1 (late blocks must not see the new one).
 // next.kind == -2: finalize only and advance the chain's sweep counter (closing launch of a sweep).
-template <bool WF>
+template <int NCH>
 __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec next,
                                                   int have_prev, int pbuf) {
-    extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // block 0: rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
+    extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // block 0: rg [M] | rt [M]
     __shared__ MvShared sm;
     __shared__ Move pend;
     __shared__ double2 ltab[LOGTAB_N];
@@ -914,9 +602,6 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
         int *rtl = dyn_i + M;
         L.rt = rtl;
         L.rg = dyn_i;
-        L.rk = dyn_i + 2 * M;
-        L.rsrc = L.rk + MMAX * (T + 1);
-        L.rdst = L.rsrc + MMAX * (T + 1);
         const bool patch = have_prev && s_acc && pend.tgt == next.tgt;
         if (next.kind == 0) {
             // row totals of the target plane: prefetched values (+ what the accepted update moved)
@@ -957,7 +642,7 @@ __global__ __launch_bounds__(MVB) void k_move_pa2(Dims d, Consts c, Work w, Samp
 #ifdef SEIR_STAMPS
         L.stamp_hs = stamp_hs; L.stamp_on = stamp_on;
 #endif
-        mv_propose<WF>(d, w, s, ch, b, next, sm, L, ltab);
+        mv_propose<NCH>(d, w, s, ch, b, next, sm, L, ltab);
         MSTAMP(10);
         if (tid == 0) ch.mv[(size_t)(pbuf ^ 1) * s.B + b] = sm.mv;
         MSTAMP(11);
@@ -1323,11 +1008,11 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     (void)sh_cn;
 }
 
-template <bool WF>
+template <int NCH>
 __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
                                                    MoveSpec next, MoveSpec se_next, int have_prev, int have_pre,
                                                    int pbuf, int nbk, int lidx, int dbg, int nband) {
-    extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // rg [M] | rt [M] | rk, rsrc, rdst [MMAX][T+1]
+    extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // rg [M] | rt [M]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
     __shared__ PairNote note;
@@ -1427,9 +1112,6 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     int *rtl = dyn_i + M;
     L.rt = rtl;
     L.rg = dyn_i;
-    L.rk = dyn_i + 2 * M;
-    L.rsrc = L.rk + MMAX * (T + 1);
-    L.rdst = L.rsrc + MMAX * (T + 1);
     // ---- (1) the pending E->I-type proposal: every role needs the decision, role 0 acts on it
     bool pend_acc = false;
     const Move *pendp = nullptr;
@@ -1452,7 +1134,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         L.stamp_hs = stamp_hs; L.stamp_on = rstamp_on;
 #endif
         mv_rows_to_lds(d, w, s, b, mine, pre_ok, pre_nx, fix, L, rtl);
-        mv_propose<WF>(d, w, s, ch, b, mine, sm_nx, L, ltab);
+        mv_propose<NCH>(d, w, s, ch, b, mine, sm_nx, L, ltab);
         RSTAMP(10);
         Move *out = (role == 1 ? ch.mv : ch.mvs) + (size_t)(pbuf ^ 1) * s.B + b;
         move_copy(out, &sm_nx.mv, MVB - WAVE);             // by the last wave: nobody's loads queue behind the store
@@ -1570,7 +1252,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
             // the pending update was of the other plane (tgt 1): nothing to correct in plane 0's totals
             mv_rows_to_lds(d, w, s, b, se, pre_ok, pre_se, nullptr, L, rtl);
             PSTAMP(2);
-            mv_propose<WF>(d, w, s, ch, b, se, sm_se, L, ltab);
+            mv_propose<NCH>(d, w, s, ch, b, se, sm_se, L, ltab);
             PSTAMP(3);
         }
         const Move &mv = sm_se.mv;
@@ -1614,7 +1296,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
             const Move *fix = (pend_acc && pendp->tgt == next.tgt) ? pendp : nullptr;
             mv_rows_to_lds(d, w, s, b, next, pre_ok, pre_nx, fix, L, rtl);
             PSTAMP(6);
-            mv_propose<WF>(d, w, s, ch, b, next, sm_nx, L, ltab, /*rows_only=*/true);
+            mv_propose<NCH>(d, w, s, ch, b, next, sm_nx, L, ltab, /*rows_only=*/true);
         }
         if (tid == 0) {
             int conf = late ? 1 : 0;                         // role 1 was not there in time: do not trust it
@@ -1631,7 +1313,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         }
         lds_barrier();
         if (s_conf) {                                        // rare: draw it again from the final state
-            mv_propose<WF>(d, w, s, ch, b, next, sm_nx, L, ltab);
+            mv_propose<NCH>(d, w, s, ch, b, next, sm_nx, L, ltab);
             move_copy(ch.mvfix + (size_t)(pbuf ^ 1) * s.B + b, &sm_nx.mv, MVB - WAVE);
             const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
             mv_own_rows_to_down(d, c, w, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred,
@@ -1670,7 +1352,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
 }
 
 inline size_t k_move_pa2_lds_bytes(const Dims &d) {
-    return sizeof(int) * ((size_t)2 * d.M + 3 * MMAX * (d.T + 1));
+    return sizeof(int) * ((size_t)2 * d.M);
 }
 
 }  // namespace seir

@@ -98,6 +98,8 @@ struct Chains {
                                                          //     one line made every ticket a cross-XCD transaction (+14 us per launch);
                                                          //     then [B][TAIL_FLAG_STRIDE]: the count at which the chain's last tile raised
                                                          //     the flag the roles poll
+    unsigned long long *leap;                            // [B][LEAP_CH] k_leap's counters and flags (see there), a chain's in its own 8 KB
+    unsigned long long *leap_st;                         // [B][16][8] developer timeline of k_leap (LEAP_STAMPS builds only)
     unsigned *hand2;                                     // [B] the same token for role 2 (pre-drawn S->E-type proposal)
     Move *mvs;                                           // [2][B] S->E-type proposal pre-drawn for the next launch (k_move_pair, role 2)
     double *DownS;                                       // [2][B][2] its own-rows log-ratio {theta, const}
@@ -790,18 +792,26 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
 // wait(): called once, after every load that does not depend on this launch's partial sums has been issued and
 // before the first one that does (k_se_chunk: the spin on the chain's tile counter goes there, so those loads and
 // the wait overlap); a no-op in k_hmc_chunk.
-template <int NTC, bool COH, typename Wait>
+// PERS (k_leap: all inner steps in ONE launch): what the previous step's roles wrote -- position and momentum, the
+// global parameters, the chunk sums, the spatial effects -- was written by workgroups of this same launch too, so those
+// are read past the L1 as well (the caller makes sure every role of the previous step has finished).
+template <int NTC, bool COH, bool PERS = false, typename Wait>
 __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
-                                               const Chains &ch, int par, int bx, int b, Wait wait) {
+                                               const Chains &ch, int par, int bx, int b, Wait wait, int lane_in = -1) {
     __shared__ double2 ltab[LOGTAB_N];
     auto LDP = [](const double *p_) {
         return COH ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_;
+    };
+    auto LDQ = [](const double *p_) {
+        return PERS ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_;
     };
     constexpr int NC = NTC > 0 ? NTC : CT_MAXC;
     const int T = d.T, M = d.M, nmt = d.nmt;
     const int ntc = NTC > 0 ? NTC : d.ntc;
     const int ntile = nmt * ntc;
-    const int lane = threadIdx.x;
+    // (k_leap passes the lane id through an opaque move made inside its step loop: every per-lane address then depends
+    // on something defined in the loop, and the compiler cannot hoist -- and then spill -- a few dozen 64-bit addresses)
+    const int lane = PERS ? lane_in : (int)threadIdx.x;
     double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp;
     const double *var = ch.var + (size_t)b * d.Pp;
     double *sc = w.scal + (size_t)b * NSCAL;
@@ -816,22 +826,40 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const bool own = t >= 1 && t < T;
         ltab[lane] = c.logtab[lane];
         ltab[lane + WAVE] = c.logtab[lane + WAVE];
-        const double alpha = own ? q[oT + t] : 0.0, pm = own ? p[oT + t] : 0.0, v = own ? var[oT + t] : 0.0;
+        const double alpha = own ? LDQ(q + oT + t) : 0.0, pm = own ? LDQ(p + oT + t) : 0.0, v = own ? var[oT + t] : 0.0;
         const double wd_t = c.wd[t];
-        const double a0 = gr[5], g0 = gr[3], g1 = gr[4], pa0 = gr[11], pg0 = gr[9], pg1 = gr[10];
+        const double a0 = LDQ(gr + 5), g0 = LDQ(gr + 3), g1 = LDQ(gr + 4), pa0 = LDQ(gr + 11), pg0 = LDQ(gr + 9), pg1 = LDQ(gr + 10);
         const double va0 = var[5], vg0 = var[3], vg1 = var[4];
         // V at the chunk ends, the chunk sums of the current position (chunk = lane)
         double vend[NC];
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) vend[cc] = cc < ntc ? w.Vt[(size_t)b * d.Tp + cc * WAVE + WAVE - 1] : 0.0;
         const double *ctr = w.CT + (((size_t)b * 2 + par) * CT_MAXC) * 4;
-        const double cta_l = lane < ntc ? ctr[lane * 4] : 0.0, ctvp_l = lane < ntc ? ctr[lane * 4 + 1] : 0.0,
-                     ctva_l = lane < ntc ? ctr[lane * 4 + 2] : 0.0;
+        const double cta_l = lane < ntc ? LDQ(ctr + lane * 4) : 0.0, ctvp_l = lane < ntc ? LDQ(ctr + lane * 4 + 1) : 0.0,
+                     ctva_l = lane < ntc ? LDQ(ctr + lane * 4 + 2) : 0.0;
         // I->R gradient (gamma0, gamma1): the chunks' parts, left by the previous step (Work::CG) -- ntc pairs instead
         // of one series evaluation per day of the whole series in every chunk
         const double *cgr = w.CG + (((size_t)b * 2 + par) * CT_MAXC) * 2;
-        const double cg0_l = lane < ntc ? cgr[lane * 2] : 0.0, cg1_l = lane < ntc ? cgr[lane * 2 + 1] : 0.0;
+        const double cg0_l = lane < ntc ? LDQ(cgr + lane * 2) : 0.0, cg1_l = lane < ntc ? LDQ(cgr + lane * 2 + 1) : 0.0;
         const double kir_t = t < T ? w.Kir[(size_t)b * d.Tp + t] : 0.0, dir_t = t < T ? w.Dir[(size_t)b * d.Tp + t] : 0.0;
+        // The I->R part of the step needs nothing of this step's tiles -- gamma0 and gamma1 move by the chunk parts the
+        // previous step left (Work::CG) -- so all of it (two wave sums, the new rates, the series, two more wave sums: half of
+        // the role's dependent operations) runs BEFORE the wait, under the tile phase.  Same operations, same results.
+        lds_barrier();                                     // ltab (single wave: orders the LDS writes)
+        const double gg0 = wave_sum(cg0_l), gg1 = wave_sum(cg1_l);
+        const double pg0n = pg0 + eps * (gg0 - g0 / 1.0e4), g0n = g0 + eps * vg0 * pg0n;
+        const double pg1n = pg1 + eps * (gg1 - g1 / 1.0e4), g1n = g1 + eps * vg1 * pg1n;
+        double ng0p = 0.0, ng1p = 0.0, rnew = 0.0;
+        if (t < T) {
+            rnew = exp(g0n + g1n * wd_t);
+            // this chunk's part of the I->R gradient at the new rates, for the next step
+            double L, inv;
+            l1me_inv_wide(rnew * d.dt, L, inv, ltab);
+            const double grr = d.dt * ((kir_t != 0.0 ? kir_t * inv : 0.0) - dir_t);
+            ng0p = grr * rnew;
+            ng1p = grr * rnew * wd_t;
+        }
+        const double ng0s = wave_sum(ng0p), ng1s = wave_sum(ng1p);
         wait();
         // ---- from here on: this step's partial sums
         // column sums of this chunk
@@ -875,8 +903,6 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                 for (int cc = c0; cc < c0 + 3 && cc < NC; ++cc) asm volatile("" : "+v"(bs[cc]), "+v"(as[cc]));   // the sums, here
             }
         }
-        lds_barrier();                                     // ltab (single wave: orders the LDS writes)
-        const double gg0 = wave_sum(cg0_l), gg1 = wave_sum(cg1_l);
         // Everything that couples the chunks is linear in the tile scalars, so each lane forms its
         // row tile's share and three wave sums finish the job:
         //   later = sum_{c' > ci} B(c'),  allB = sum B,
@@ -901,25 +927,14 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const double pn = own ? pm + eps * g : 0.0;
         const double an = own ? alpha + eps * v * pn : 0.0;
         const double pa0n = pa0 + eps * (allB - a0 / 100.0), a0n = a0 + eps * va0 * pa0n;
-        const double pg0n = pg0 + eps * (gg0 - g0 / 1.0e4), g0n = g0 + eps * vg0 * pg0n;
-        const double pg1n = pg1 + eps * (gg1 - g1 / 1.0e4), g1n = g1 + eps * vg1 * pg1n;
         const double a_new = a0n + pre + wave_incl_scan(an, lane);
         if (own) { q[oT + t] = an; p[oT + t] = pn; }
-        double ng0p = 0.0, ng1p = 0.0;
         if (t < T) {
             w.acur[(size_t)b * d.Tp + t] = a_new;
             w.ea[(size_t)b * d.Tp + t] = exp(a_new);
-            const double rnew = exp(g0n + g1n * wd_t);
             w.rir[(size_t)b * d.Tp + t] = rnew;            // read by nobody in this launch
-            // this chunk's part of the I->R gradient at the new rates, for the next step
-            double L, inv;
-            l1me_inv_wide(rnew * d.dt, L, inv, ltab);
-            const double grr = d.dt * ((kir_t != 0.0 ? kir_t * inv : 0.0) - dir_t);
-            ng0p = grr * rnew;
-            ng1p = grr * rnew * wd_t;
         }
         const double ca = wave_sum(an), cvp = wave_sum(v * pn), cva = wave_sum(v * an);
-        const double ng0s = wave_sum(ng0p), ng1s = wave_sum(ng1p);
         if (lane == 0) {
             double *ctw = w.CT + (((size_t)b * 2 + (par ^ 1)) * CT_MAXC + ci) * 4;
             ctw[0] = ca; ctw[1] = cvp; ctw[2] = cva;
@@ -937,10 +952,10 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const bool own = m < M;
         const double *spr = w.sp + ((size_t)b * 2 + par) * d.Mp;
         double *spw = w.sp + ((size_t)b * 2 + (par ^ 1)) * d.Mp;
-        const double sm = own ? q[oM + m] : 0.0, pm = own ? p[oM + m] : 0.0, v = own ? var[oM + m] : 0.0;
+        const double sm = own ? LDQ(q + oM + m) : 0.0, pm = own ? LDQ(p + oM + m) : 0.0, v = own ? var[oM + m] : 0.0;
         const double lm = own ? c.la[m] : 0.0, inN = own ? c.invN[m] : 0.0;
-        const double u0 = gr[0], u1 = gr[1], beta = gr[2], p0 = gr[6], p1 = gr[7], p2 = gr[8];
-        const double psi = gr[12], sig = gr[13], s0 = gr[14], s1 = gr[15];
+        const double u0 = LDQ(gr + 0), u1 = LDQ(gr + 1), beta = LDQ(gr + 2), p0 = LDQ(gr + 6), p1 = LDQ(gr + 7), p2 = LDQ(gr + 8);
+        const double psi = LDQ(gr + 12), sig = LDQ(gr + 13), s0 = LDQ(gr + 14), s1 = LDQ(gr + 15);
         const double v0 = var[0], v1 = var[1], v2 = var[2];
         double Qs = 0.0;                                   // (Q s)_m at the current position
         if (own) {
@@ -954,11 +969,11 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                 }
                 double sv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sv[j] = spr[qc[j]];
+                for (int j = 0; j < 8; ++j) sv[j] = LDQ(spr + qc[j]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Qs += qv[j] * sv[j];
             } else {
-                for (int e = c.Qrow[m]; e < c.Qrow[m + 1]; ++e) Qs += c.Qval[e] * spr[c.Qcol[e]];
+                for (int e = c.Qrow[m]; e < c.Qrow[m + 1]; ++e) Qs += c.Qval[e] * LDQ(spr + c.Qcol[e]);
             }
         }
         const bool rows_here = d.chunked == 1;             // small M: sum_m l_m R_m, sum_m s_m R_m from the row partials
@@ -1003,7 +1018,8 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                     const int mc = on ? mm : 0;
                     const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + mc;
                     lx[kk] = on ? c.la[mc] : 0.0;
-                    sx[kk] = on ? spr[mc] : 0.0;
+                    const double sv_ = LDQ(spr + mc);              // (clamped index + select: no branch around the load)
+                    sx[kk] = on ? sv_ : 0.0;
 #pragma unroll
                     for (int j = 0; j < NC; ++j) {
                         const double v_ = LDP(rp + (size_t)(j < ntc ? j : 0) * d.Mp);
@@ -1146,6 +1162,321 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_max(stp + 4, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_leap: ALL inner leapfrog steps 1..L-1 of a trajectory in ONE persistent launch.
+//
+// During a trajectory the events are fixed: of the 20 B per cell a gradient tile reads (F fp64; I, k_se, S int32) nothing
+// changes from step to step -- only the T + M table entries exp(a_t), exp(b_m)/N_m and psi do.  k_se_chunk, one launch per
+// step, streams those 24.5 MB (UK-380, 8 chains) through the fabric again for every one of the 15 steps; here a tile
+// workgroup loads its 16 x 64 cells ONCE, keeps them in registers (4 cells x 20 B = 20 VGPRs per lane) and per step reads
+// only its 64 + 16 table entries and writes its partial sums.  Grid and roles as in k_se_chunk (tile blocks, then one
+// single-wave workgroup per 64-day / 64-row chunk role), all of a chain's workgroups on one XCD (checked at creation),
+// every workgroup of the launch resident at once (checked by the host through the occupancy query: tiles wait here).
+// Two one-directional hand-offs per step, both through the XCD's L2 without fences (see k_se_chunk), in the chain's
+// own block of Chains::leap.  Returning atomics on ONE address are served one after the other, ~26 ns apiece (timeline:
+// 144 tiles that finish together were counted in over 3.7 us), so the tiles count in on LEAP_NSH counters in lines of
+// their own (tile t on counter t mod 8) and whoever completes a counter raises that counter's flag:
+//   tiles -> roles  a role waits until all (up to) eight flags show the step (one load per lane 0..7, one ballot);
+//   roles -> tiles  one counter (twelve roles, each after its stores are acknowledged: s_waitcnt vmcnt(0)); the role that
+//                   completes the step's count writes the step number to eight flag words in eight lines, and a tile --
+//                   or a role, before it reads what the previous step's roles wrote -- polls copy (index mod 8).
+// Everything a workgroup reads that another workgroup of this launch wrote is read past the L1 (agent-scope loads).
+// The arithmetic is se_tile's and hmc_chunk_role's, operand for operand and in the same order: results are
+// bit-identical to k_se_chunk and to k_se + k_hmc_chunk (tests/test_sampler_gpu.py).
+// Every wait is bounded; a time-out is counted in Chains::late (fatal part) and the workgroup goes on, so the grid
+// always drains.
+// ---------------------------------------------------------------------------------------------
+constexpr int LEAP_BACKOFF = 12;     // x 64 cycles slept before a tile first looks for the roles' flag
+constexpr int LEAP_NSH = 8;          // counters / flag copies per chain, 128 bytes apart
+constexpr int LEAP_CH = 1024;        // 64-bit words of Chains::leap per chain
+#define LEAP_CNT1(b_, k_) (ch.leap + (size_t)(b_) * LEAP_CH + (k_) * 16)            // tiles counted in on shard k, over all launches
+#define LEAP_FLAG1(b_, k_) (ch.leap + (size_t)(b_) * LEAP_CH + 128 + (k_) * 16)     // last step whose shard-k tiles are all in
+#define LEAP_CNT2(b_) (ch.leap + (size_t)(b_) * LEAP_CH + 256)                      // roles done, over all launches
+#define LEAP_FLAG2(b_, k_) (ch.leap + (size_t)(b_) * LEAP_CH + 272 + (k_) * 16)     // last step whose roles are all done (8 copies)
+#ifdef LEAP_STAMPS
+// developer timeline (tools/dev/leap_timeline.py): per chain and step, min / max over the tile workgroups of "past the wait
+// for the tables" (0, 1) and "counted in" (2, 3), min / max over the roles of "past the wait for the tiles" (4, 5) and "done" (6, 7)
+// (LEAP_STAMPS=2; they are atomics on one line per chain and stretch what they time: =1 keeps only the probes below)
+#if LEAP_STAMPS >= 2
+#define LSTAMP_MIN(k) __hip_atomic_fetch_min(ch.leap_st + ((size_t)b * 16 + (it & 15)) * 8 + (k), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LSTAMP_MAX(k) __hip_atomic_fetch_max(ch.leap_st + ((size_t)b * 16 + (it & 15)) * 8 + (k), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define LSTAMP_MIN(k) do {} while (0)
+#define LSTAMP_MAX(k) do {} while (0)
+#endif
+// and of two tile workgroups of chain 0 (the first and one in the middle) and two roles (T-chunk 0, M-chunk 0): plain stores of their own
+// stamps, tiles behind the chains' blocks, roles in the blocks of chains 1 and 2
+#define LPROBE(k) do { if (b == 0 && threadIdx.x == 0 && (tix == 0 || tix == nwg / 2 + 5)) \
+    ch.leap_st[((size_t)s.B * 16 + (tix == 0 ? 0 : 16) + (it & 15)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// every tile workgroup of chain 0 in step 7: [tix][k], behind the probes' blocks (k = 0 past the wait, 1 cells done, 2 counted in, 3 HW_ID)
+#define LALL(k) do { if (b == 0 && threadIdx.x == 0 && it == 7 && tix < 1024) \
+    ch.leap_st[((size_t)s.B + 2) * 128 + (size_t)tix * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RPROBE(k) do { if (b == 0 && threadIdx.x == 0 && (role == 0 || role == d.ntc)) \
+    ch.leap_st[((size_t)(role == 0 ? 1 : 2) * 16 + (it & 15)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LSTAMP_MIN(k) do {} while (0)
+#define LSTAMP_MAX(k) do {} while (0)
+#define LPROBE(k) do {} while (0)
+#define LALL(k) do {} while (0)
+#define RPROBE(k) do {} while (0)
+#endif
+__device__ __forceinline__ void leap_wait(const unsigned long long *flag, unsigned long long target, unsigned *late) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { if ((threadIdx.x & 63) == 0) *late += 1; break; }   // ~0.1 s: never seen; counted, no hang
+    }
+}
+
+// NST: 16-row gradient tiles per workgroup (the same day chunk, consecutive row tiles) -- wave w owns rows 4w..4w+3 of each of
+// them, NST x 4 cells per lane.  Each tile's sums are formed exactly as se_tile forms them (bit-identical partial sums,
+// whatever NST); what grows with NST is the work per wave and what shrinks is everything paid per workgroup: arrivals on
+// the chain's counters, polls, barriers, reductions' fixed parts, and the number of waves the literals of the polynomials
+// are materialised for.
+template <int TSM, int NST>
+__device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s, const Chains &ch,
+                                          int bx, int byg, int bz, int par0, int nsteps, unsigned long long step_base) {
+    __shared__ double colbuf[NST][4][WAVE];
+    __shared__ double llbuf[NST][4][WAVE], psibuf[NST][4][WAVE];
+    __shared__ double rowbuf[NST][4 * SE_RW * SE_RS];
+    __shared__ double rlbuf[TSM == 2 ? NST : 1][4][WAVE], rsbuf[TSM == 2 ? NST : 1][4][WAVE];
+    __shared__ double2 ltab[LDSTAB_N];
+    // the step's tables, fetched past the L1 by one wave each and handed to the others through LDS: exp(a_t) of the 64 days
+    // (wave 0) | exp(b_m)/N_m of the rows (wave 1) | the rows' spatial effects (TSM 2, wave 2) | psi (wave 3).  With every
+    // wave loading its own operands the 576 waves of a chain all asked the L2 for the same few lines at the same moment
+    __shared__ double tabbuf[WAVE + 2 * NST * SE_TM + 8];
+    constexpr int TB_EB = WAVE, TB_SP = WAVE + NST * SE_TM, TB_PSI = WAVE + 2 * NST * SE_TM;
+    static_assert(NST * SE_TM <= WAVE, "one wave fetches the rows' table entries");
+    auto LDP = [](const double *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    debug_skew(d);
+    const int b = d.b0 + bz, wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    const int t0 = bx * WAVE + lane0;
+    const int mg = byg * NST * SE_TM;                            // first row of the workgroup's tiles
+    const int ntile = d.ntc * d.nmt, nwg = ntile / NST;          // gradient tiles / tile workgroups of a chain
+    if (threadIdx.x < LOGTAB_N) ltab[threadIdx.x] = c.logtab[threadIdx.x];
+    // ---- the step-invariant operands, once: the tiles' cells in registers, the per-day and per-row constants
+    const double Wt = c.W[t0];
+    double F[NST][SE_RW];
+    int Ii[NST][SE_RW], ki[NST][SE_RW], si[NST][SE_RW];
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int r = 0; r < SE_RW; ++r) {
+            const size_t q = ((size_t)b * d.Mp + mg + st * SE_TM + wave * SE_RW + r) * d.Tp + t0;
+            F[st][r] = w.F[q];
+            ki[st][r] = w.K[0][q];
+            Ii[st][r] = w.St[2][q];
+            si[st][r] = w.St[0][q];
+        }
+    constexpr bool ts_rows = TSM == 2;
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    double ts_l[NST][SE_RW];
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int r = 0; r < SE_RW; ++r) ts_l[st][r] = ts_rows ? c.la[mg + st * SE_TM + wu * SE_RW + r] : 0.0;
+    const double ts_vt = w.Vt[(size_t)b * d.Tp + t0];
+    // this workgroup's shard of the chain's counters: workgroups g, g + nsh, g + 2 nsh ... count in together
+    const int tix = byg * d.ntc + bx, nsh = min(LEAP_NSH, nwg), shard = tix % nsh;
+    const unsigned long long shard_size = (unsigned long long)((nwg - shard + nsh - 1) / nsh);
+    const unsigned long long *flag2 = LEAP_FLAG2(b, shard);
+    unsigned long long *cnt1 = LEAP_CNT1(b, shard), *flag1 = LEAP_FLAG1(b, shard);
+    __syncthreads();                                             // ltab
+    for (int it = 0; it < nsteps; ++it) {
+        const int par = par0 ^ (it & 1);
+        // (opaque copies made inside the loop: the per-lane addresses of the step are then not loop-invariant for the
+        // compiler, which would otherwise hoist a few dozen of them out of the loop and spill them)
+        int lane = lane0, t = t0;
+        asm volatile("" : "+v"(lane), "+v"(t));
+        {
+            // every wave waits (from the second step on) for the tables of this step's position, written by the roles of
+            // step it-1, and fetches its share: four requests per workgroup
+            const bool fetch = wu == 0 || wu == 1 || wu == 3 || (ts_rows && wu == 2);
+            if (it > 0 && fetch) {
+                __builtin_amdgcn_s_sleep(LEAP_BACKOFF);
+                leap_wait(flag2, step_base + (unsigned long long)it, ch.late + ch.late_fatal + b);
+            }
+            if (threadIdx.x == 0) { LSTAMP_MIN(0); LSTAMP_MAX(1); }
+            LPROBE(0);
+            LALL(0);
+            if (wu == 0) {
+                tabbuf[lane] = LDP(w.ea + (size_t)b * d.Tp + t);
+            } else if (wu == 1) {
+                if (lane < NST * SE_TM) tabbuf[TB_EB + lane] = LDP(w.eb + (size_t)b * d.Mp + mg + lane);
+            } else if (wu == 2) {
+                if (ts_rows && lane < NST * SE_TM) tabbuf[TB_SP + lane] = LDP(w.sp + ((size_t)b * 2 + par) * d.Mp + mg + lane);
+            } else {
+                if (lane == 0) tabbuf[TB_PSI] = LDP(w.scal + (size_t)b * NSCAL + SC_PSI);
+            }
+        }
+        SeK sk;
+        sk.load();                                               // the series' literals as scalars (device_math.h), per step
+        __syncthreads();
+        LPROBE(1);                                               // tables in LDS
+        const double psi = tabbuf[TB_PSI];
+        const double ea_t = tabbuf[lane];
+        const double psiW = psi * Wt;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            double eb[SE_RW], ts_s[SE_RW];
+#pragma unroll
+            for (int r = 0; r < SE_RW; ++r) {
+                eb[r] = tabbuf[TB_EB + st * SE_TM + wave * SE_RW + r];
+                ts_s[r] = ts_rows ? tabbuf[TB_SP + st * SE_TM + wave * SE_RW + r] : 0.0;
+            }
+            double *myrow = rowbuf[st] + wave * SE_RW * SE_RS;
+            double ll = 0.0, gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0;
+            // the four cells side by side (se_cells: se_tile's own evaluation)
+            double Id[SE_RW], ee[SE_RW], lam0[SE_RW], rr[SE_RW], L[SE_RW], inv[SE_RW];
+#pragma unroll
+            for (int r = 0; r < SE_RW; ++r) Id[r] = (double)Ii[st][r];
+            se_cells<SE_RW>(ea_t, eb, Id, psiW, F[st], d.rate_floor, d.dt, ltab, sk, ee, lam0, rr, L, inv);
+#pragma unroll
+            for (int r = 0; r < SE_RW; ++r) {
+                const double kse = (double)ki[st][r], snk = (double)(si[st][r] - ki[st][r]);
+                const bool has = kse != 0.0;
+                ll += (has ? kse * L[r] : 0.0) - snk * rr[r];
+                const double gl = d.dt * ((has ? kse * inv[r] : 0.0) - snk);
+                const double ge = gl * lam0[r];
+                myrow[r * SE_RS + lane] = ge;
+                colacc += ge;
+                if (ts_rows) {
+                    rlacc = fma(ge, ts_l[st][r], rlacc);
+                    rsacc = fma(ge, ts_s[r], rsacc);
+                }
+                gpsi += gl * ee[r] * Wt * F[st][r];
+            }
+            llbuf[st][wave][lane] = ll;
+            psibuf[st][wave][lane] = gpsi;
+            colbuf[st][wave][lane] = colacc;
+            {
+                constexpr int LPR = WAVE / SE_RW;
+                const int rr_ = lane / LPR, ss = lane % LPR;
+                const double *src = myrow + rr_ * SE_RS + ss;
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < SE_RW; j += 2) v += src[j * LPR] + src[(j + 1) * LPR];
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, WAVE);
+                if (ss == 0) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + mg + st * SE_TM + wave * SE_RW + rr_] = v;
+                if (ts_rows) { rlbuf[st][wave][lane] = rlacc; rsbuf[st][wave][lane] = rsacc; }
+            }
+        }
+        LPROBE(2);                                               // cells done (wave 0)
+        LALL(1);
+        __syncthreads();
+        LPROBE(3);                                               // past the middle barrier
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int by = byg * NST + st;
+            const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
+            if (wave == 0) {
+                const double v = wave_sum((llbuf[st][0][lane] + llbuf[st][1][lane]) + (llbuf[st][2][lane] + llbuf[st][3][lane]));
+                if (lane == 0) w.Lpart[tile] = v;
+            } else if (wave == 1) {
+                const double v = wave_sum((psibuf[st][0][lane] + psibuf[st][1][lane]) + (psibuf[st][2][lane] + psibuf[st][3][lane]));
+                if (lane == 0) w.Ppart[tile] = v;
+            } else if (wave == 2) {
+                const double cs = (colbuf[st][0][lane] + colbuf[st][1][lane]) + (colbuf[st][2][lane] + colbuf[st][3][lane]);
+                w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t] = cs;
+                if (ts_rows) {
+                    const double bs = wave_sum(cs), as = wave_sum(cs * ts_vt);
+                    if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
+                }
+            } else {
+                if (!ts_rows) {
+                    const double cs = (colbuf[st][0][lane] + colbuf[st][1][lane]) + (colbuf[st][2][lane] + colbuf[st][3][lane]);
+                    const double bs = wave_sum(cs), as = wave_sum(cs * ts_vt);
+                    if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
+                }
+                if (ts_rows) {
+                    const double rl = wave_sum((rlbuf[st][0][lane] + rlbuf[st][1][lane]) + (rlbuf[st][2][lane] + rlbuf[st][3][lane]));
+                    const double rs = wave_sum((rsbuf[st][0][lane] + rsbuf[st][1][lane]) + (rsbuf[st][2][lane] + rsbuf[st][3][lane]));
+                    if (lane == 0) { w.TS[tile * 4 + 2] = rl; w.TS[tile * 4 + 3] = rs; }
+                }
+            }
+        }
+        LPROBE(4);                                               // wave 0's reductions issued
+        __syncthreads();                                         // vmcnt(0): this step's partial sums are in the XCD's L2
+        LPROBE(5);                                               // stores acknowledged
+        if (threadIdx.x == 0) {
+            const unsigned long long stepno = step_base + (unsigned long long)(it + 1);
+            const unsigned long long old = __hip_atomic_fetch_add(cnt1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == stepno * shard_size) __hip_atomic_store(flag1, stepno, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LSTAMP_MIN(2); LSTAMP_MAX(3);
+            LPROBE(6);                                           // counted in (the atomic has returned)
+            LALL(2);
+#ifdef LEAP_STAMPS
+            if (b == 0 && it == 7 && tix < 1024) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                ch.leap_st[((size_t)s.B + 2) * 128 + (size_t)tix * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+            }
+#endif
+        }
+    }
+}
+
+constexpr int leap_waves_per_simd(int nst) { return nst == 1 ? 5 : 3; }
+template <int TSM, int NTC, int NST>
+__global__ __launch_bounds__(256, NTC == 12 ? (leap_waves_per_simd(NST) < 3 ? leap_waves_per_simd(NST) : 3) : leap_waves_per_simd(NST))
+void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nsteps, unsigned long long step_base) {
+    const int nwg = d.ntc * d.nmt / NST, n_tiles = nwg * d.aff_nb;   // tile workgroups per chain: NST gradient tiles each
+    const int nroles = d.ntc + d.Mp / WAVE;
+    if ((int)blockIdx.x < n_tiles) {
+        int bz, tile;
+        xcd_affine(blockIdx.x, nwg, d.aff_nb, bz, tile);
+        if (d.nlive > 0 && bz >= d.nlive) return;      // a chain of the layout that does not exist
+        leap_tile<TSM, NST>(d, c, w, s, ch, tile % d.ntc, tile / d.ntc, bz, par0, nsteps, step_base);
+        return;
+    }
+    if (threadIdx.x >= WAVE) return;                   // a role is one wave
+    const int L = (int)blockIdx.x - n_tiles;
+    const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
+    if (d.nlive > 0 && bz >= d.nlive) return;
+    debug_skew(d);
+    const int nsh = min(LEAP_NSH, nwg);
+    const unsigned long long *flag1 = LEAP_FLAG1(b, (int)threadIdx.x < nsh ? (int)threadIdx.x : 0);   // lane k < nsh looks at shard k
+    unsigned long long *cnt2 = LEAP_CNT2(b);
+    const unsigned long long *flag2 = LEAP_FLAG2(b, role & (LEAP_NSH - 1));
+    unsigned *late = ch.late + ch.late_fatal + b;
+    for (int it = 0; it < nsteps; ++it) {
+        // nothing of a role lives across the steps: without this the compiler hoists the step-invariant loads of the role
+        // (variances, V(t), the I->R statistics, CAR rows ...) out of the loop and spills 500+ bytes per lane to hold them
+        asm volatile("" ::: "memory");
+        const int par = par0 ^ (it & 1);
+        // what the roles of the previous step wrote (chunk sums, global parameters, spatial effects, q and p)
+        if (it > 0) leap_wait(flag2, step_base + (unsigned long long)it, late);
+        RPROBE(0);                                               // the previous step's roles are done
+        const unsigned long long stepno = step_base + (unsigned long long)(it + 1);
+        int lane_op = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane_op));
+        hmc_chunk_role<NTC, true, true>(d, c, w, s, ch, par, role, b, [&] {
+            if (nwg >= 32) __builtin_amdgcn_s_sleep(LEAP_BACKOFF);
+            int spins = 0;                                       // every shard's tiles are in: all of (up to) eight flags show the step
+            while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(flag1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stepno) != 0ull) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { if (threadIdx.x == 0) *late += 1; break; }
+            }
+            if (threadIdx.x == 0) { LSTAMP_MIN(4); LSTAMP_MAX(5); }
+            RPROBE(1);                                           // the step's tiles are in
+        }, lane_op);
+        RPROBE(2);                                               // stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this role's stores are in the XCD's L2
+        RPROBE(3);
+        {
+            unsigned long long old = 0ull;
+            if (threadIdx.x == 0) old = __hip_atomic_fetch_add(cnt2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = __builtin_amdgcn_readfirstlane((int)(old + 1 == stepno * (unsigned long long)nroles)) != 0;
+            if (last && threadIdx.x < LEAP_NSH)                  // the step's last role: eight copies of the flag, one store
+                __hip_atomic_store(LEAP_FLAG2(b, threadIdx.x), stepno, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) { LSTAMP_MIN(6); LSTAMP_MAX(7); }
+            RPROBE(4);                                           // counted in
+        }
+    }
 }
 
 // XCC_ID of every workgroup of a grid laid out like the XCD-affine grids: the host checks that blocks with the same

@@ -54,6 +54,7 @@ struct seir_ctx {
     bool prepared = false;
     int opt_skew = 0, opt_affinity = 3;     // seir_set_option
     int opt_gemm_f32 = 0;
+    int opt_leap_nst = 0;          // SEIR_OPT_LEAP_NST: gradient tiles per workgroup of k_leap (0 = the largest that fits)
     int opt_eval_form = 0;            // 0 auto (one launch where a chain's blocks share an XCD, else three), 1 four launches, 2 three
     int xcd_local = -1;               // -1 not probed yet; 1: blocks with the same id mod 8 share an XCD, eight different ones
     unsigned long long *eval_cnt = nullptr;   // [8][EVC_STRIDE] k_eval_all's counters
@@ -315,6 +316,10 @@ extern "C" int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value) {
         case SEIR_OPT_EVAL_FORM:
             if (value < 0 || value > 2) return fail(SEIR_ERR_INVALID, "eval form is 0 (auto), 1 (four launches) or 2 (three launches)");
             ctx->opt_eval_form = value;
+            return 0;
+        case SEIR_OPT_LEAP_NST:
+            if (value != 0 && value != 1 && value != 2) return fail(SEIR_ERR_INVALID, "leap_nst is 0 (auto), 1 or 2");
+            ctx->opt_leap_nst = value;
             return 0;
         case SEIR_OPT_GEMM_F32: {
             if (value < 0 || value > 1) return fail(SEIR_ERR_INVALID, "gemm_f32 is 0 or 1");
@@ -958,7 +963,10 @@ struct seir_sampler {
     bool copy_pending = false;
     bool use_graph = false;       // seir_sampler_desc::use_graph
     bool hmc_chunked = true;      // hmc_mode 1: every leapfrog step by the single-workgroup kernel
-    bool hmc_tail = true;         // hmc_mode 0: chunk roles inside the gradient launch (k_se_chunk) where xcd_local holds
+    bool hmc_tail = true;         // hmc_mode 0 / 3: chunk roles inside the gradient launch (k_se_chunk) where xcd_local holds
+    bool hmc_leap = true;         // hmc_mode 0: all inner steps in one persistent launch (k_leap) where every workgroup fits the chip
+    int leap_occ[2][3][2];        // workgroups of k_leap<TSM, NTC, NST> the chip holds at once (occupancy query, cached; -1: not asked yet)
+    unsigned long long leap_steps = 0;   // leapfrog steps done by all k_leap launches so far (what Chains::leap's flags show)
     bool xcd_local = false;       // blocks with the same id mod 8 share an XCD (k_xcc_probe at creation)
     unsigned long long tail_count = 0;   // tiles per chain counted in by all k_se_chunk launches so far (Chains::tail)
     int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
@@ -1022,8 +1030,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
     if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
-    if (ds->moves_mode < 0 || ds->moves_mode > 3 || ds->hmc_mode < 0 || ds->hmc_mode > 2)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..3, hmc_mode 0..2");
+    if (ds->moves_mode < 0 || ds->moves_mode > 3 || ds->hmc_mode < 0 || ds->hmc_mode > 3)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..3, hmc_mode 0..3");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
@@ -1047,7 +1055,9 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     s->use_graph = ds->use_graph != 0;
     s->pair_debug = ds->debug_pair;
     s->hmc_chunked = ds->hmc_mode != 1;
-    s->hmc_tail = ds->hmc_mode == 0;
+    s->hmc_tail = ds->hmc_mode == 0 || ds->hmc_mode == 3;
+    s->hmc_leap = ds->hmc_mode == 0;
+    for (auto &a : s->leap_occ) for (auto &b2 : a) for (int &v : b2) v = -1;
     s->moves_mode = ds->moves_mode;
     c.disable_mask = ds->disable_mask;
     {
@@ -1087,6 +1097,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.late, (size_t)2 * B);
     ch.late_fatal = B;
     S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
+    S_ALLOC(ch.leap, (size_t)B * LEAP_CH);
+    S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
     S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
     S_ALLOC(ch.hand2, (size_t)B);
     S_ALLOC(ch.mvs, (size_t)2 * B);
@@ -1353,6 +1365,14 @@ static void group_range(const seir_sampler *s, int g, int &b0, int &nb) {
     nb = (int)((long long)B * (g + 1) / G) - b0;
 }
 
+// the instance of the persistent leapfrog kernel for (tile-scalar mode, day chunks, gradient tiles per workgroup)
+static const void *leap_fn(int ts_mode, int ntc, int nst) {
+#define LEAP_ROW(TSM_, NTC_) (nst == 2 ? (const void *)k_leap<TSM_, NTC_, 2> : (const void *)k_leap<TSM_, NTC_, 1>)
+    if (ts_mode == 1) return ntc == 1 ? LEAP_ROW(1, 1) : ntc == 6 ? LEAP_ROW(1, 6) : LEAP_ROW(1, 12);
+    return ntc == 1 ? LEAP_ROW(2, 1) : ntc == 6 ? LEAP_ROW(2, 6) : LEAP_ROW(2, 12);
+#undef LEAP_ROW
+}
+
 static void enqueue_sweep(seir_sampler *s, int g) {
     seir_ctx *ctx = s->ctx;
     const SamplerCfg &c = s->cfg;
@@ -1390,7 +1410,43 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const int nbv = (nb + 7) / 8 * 8;
         const bool tail = s->hmc_tail && s->xcd_local && nbv > 0 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nbv) &&
                           !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && ts_mode != 0;
-        for (int i = 1; i < c.L; ++i) {
+        // all of them in ONE persistent launch (k_leap: the tiles keep their cells in registers over the steps) when every
+        // workgroup of that launch can be resident at once -- its tiles wait for the roles
+        bool leap = false;
+        int leap_nst = 1;
+        if (tail && s->hmc_leap && c.L >= 3) {
+            // gradient tiles per workgroup: 2 or 1 (or the one asked for: SEIR_OPT_LEAP_NST), whose launch fits the chip at
+            // once (four were measured too: 13.2 us per step against 10.4 -- 67 KB of LDS and two waves per SIMD)
+            const int ti = ts_mode - 1, ni = d0.ntc == 1 ? 0 : d0.ntc == 6 ? 1 : 2;
+            for (int k = 1; k >= 0 && !leap; --k) {
+                const int nst = 1 << k;
+                if (ctx->opt_leap_nst != 0 && ctx->opt_leap_nst != nst) continue;
+                if (d0.nmt % nst != 0) continue;
+                if (s->leap_occ[ti][ni][k] < 0) {
+                    const void *fn = leap_fn(ts_mode, d0.ntc, nst);
+                    int occ = 0, cus = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0) != hipSuccess) occ = 0;
+                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+                    s->leap_occ[ti][ni][k] = occ * cus;
+                }
+                if ((long long)(ntile_se / nst + per) * nbv <= (long long)s->leap_occ[ti][ni][k]) { leap = true; leap_nst = nst; }
+            }
+        }
+        if (leap) {
+            Dims df = l.d;
+            df.aff_nb = nbv;
+            df.nlive = nbv != nb ? nb : 0;
+            df.sp_par = 0;
+            const int nsteps = c.L - 1;
+            const dim3 gf((unsigned)((ntile_se / leap_nst + per) * nbv));
+            const unsigned long long step_base = s->leap_steps;
+            s->leap_steps += (unsigned long long)nsteps;
+            void *args[] = {(void *)&df, (void *)&ctx->c, (void *)&ctx->w, (void *)&c, (void *)&s->ch, (void *)&par, (void *)&nsteps,
+                            (void *)&step_base};
+            (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, leap_nst), gf, dim3(256), args, 0, st);
+            par = nsteps & 1;
+        }
+        for (int i = 1; i < c.L && !leap; ++i) {
             l.d.sp_par = par;
             if (tail) {
                 Dims df = l.d;
@@ -1435,9 +1491,10 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         d.aff_nb = aff ? nb : 0;
         const dim3 gm = aff ? dim3(c.nrb_d * nb) : dim3(c.nrb_d, nb);
         const size_t plds = k_move_pa2_lds_bytes(d);
-        const bool wf = d.Tp <= 6 * WAVE;                        // wave form of the proposals (moves_kernel.h)
-        auto pair_fn = wf ? k_move_pair<true> : k_move_pair<false>;
-        auto pa2_fn = wf ? k_move_pa2<true> : k_move_pa2<false>;
+        // 64-day chunks a row of the series is held in by the proposing wave (moves_kernel.h; sampler_create caps T at 1024)
+        const int nch = d.Tp <= 6 * WAVE ? 6 : d.Tp <= 12 * WAVE ? 12 : 16;
+        auto pair_fn = nch == 6 ? k_move_pair<6> : nch == 12 ? k_move_pair<12> : k_move_pair<16>;
+        auto pa2_fn = nch == 6 ? k_move_pa2<6> : nch == 12 ? k_move_pa2<12> : k_move_pa2<16>;
         if (plds > 64 * 1024 && !s->move_lds_attr) {
             (void)hipFuncSetAttribute((const void *)pair_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             (void)hipFuncSetAttribute((const void *)pa2_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
@@ -1685,6 +1742,21 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
 extern "C" int seir_debug_read_ts(seir_ctx *ctx, double *out, int64_t n) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out, ctx->w.TS, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
+#ifdef LEAP_STAMPS
+// [B][16][8] stamps of k_leap; reset = 1: min-words to ~0, max-words to 0 (call before the sweep to look at)
+extern "C" int seir_debug_leap_stamps(seir_sampler *s, unsigned long long *out, int reset) {
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    const size_t n = (size_t)(s->cfg.B + 2) * 16 * 8 + 4096;
+    HIP_TRY(hipMemcpy(out, s->ch.leap_st, n * 8, hipMemcpyDeviceToHost));
+    if (reset) {
+        std::vector<unsigned long long> h(n);
+        for (size_t i = 0; i < n; ++i) h[i] = (i & 1) ? 0ull : ~0ull;
+        HIP_TRY(hipMemcpy(s->ch.leap_st, h.data(), n * 8, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 #endif

@@ -117,6 +117,9 @@ void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context
  *                            config 5).  THIS ONE CHANGES RESULTS: F carries ~1e-7 relative error, the log-prob
  *                            ~1e-8 -- outside the 1e-9 the fp64 path is held to; off by default.  Needs
  *                            ceil64(M) and ceil64(T) to be multiples of 128.
+ *   SEIR_OPT_LEAP_NST        gradient tiles (16 rows x 64 days) per workgroup of the persistent leapfrog kernel (speed only, same
+ *                            bits): 0 (default) = 2 where that launch fits the chip at once, else 1; 1, 2 = that one or, where it
+ *                            does not fit, one launch per step
  *   SEIR_OPT_EVAL_FORM       launch form of seir_log_prob_dev (speed only): 0 (default) = the S->E term evaluated on the
  *                            contraction's accumulators and the row constants beside the matrix-core tiles, as ONE
  *                            launch for a batch of 8 or 16 chains (a multiple of 8 whose tile workgroups all fit the chip) on a
@@ -124,7 +127,7 @@ void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context
  *                            over through that XCD's L2), as three launches otherwise; 1 = the four-launch form (scan, contraction, S->E tiles, reduction); 2 = always
  *                            three launches.  0 and 2 give the same bits
  * Options are read when a launch is enqueued (for a sampler using graph replay: at capture). */
-enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2, SEIR_OPT_EVAL_FORM = 3 };
+enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2, SEIR_OPT_EVAL_FORM = 3, SEIR_OPT_LEAP_NST = 4 };
 int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value);
 
 /* Device memory helpers so that a ctypes host can keep inputs resident
@@ -197,12 +200,17 @@ typedef struct {
                                        all of a chain's workgroups share an XCD (seir_sampler_xcd_local; any number of chains in the
                                        layout of the next multiple of 8, while every workgroup of the launch fits the chip).
                                        Same draws in all four */
-    int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks, run by the last workgroups of the
-                                       gradient launch itself (k_se_chunk) when all of a chain's workgroups share
-                                       an XCD (chain b's block ids are congruent to b mod 8; checked through XCC_ID at creation), otherwise
-                                       as their own launch (k_hmc_chunk); 1: every step by the single-workgroup
-                                       kernel; 2: chunks always as their own launch (the cross-check of 0: same
-                                       bits).  0/2 against 1: same draws up to summation order */
+    int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks; all L-1 of them in ONE persistent launch
+                                       (k_leap: the gradient tiles keep their cells in registers over the steps, tiles and
+                                       chunk roles hand each other the partial sums / the next tables through the XCD's L2)
+                                       when all of a chain's workgroups share an XCD (chain b's block ids are congruent to
+                                       b mod 8; checked through XCC_ID at creation) and every workgroup of that launch fits
+                                       the chip at once; else one launch per step with the chunk roles inside the gradient
+                                       launch (k_se_chunk; needs the XCD placement only); else the chunks as their own
+                                       launch (k_hmc_chunk).  1: every step by the single-workgroup kernel; 2: chunks always
+                                       as their own launch; 3: one launch per step (k_se_chunk), never the persistent one
+                                       (2 and 3 are the cross-checks of 0: same bits).  0/2/3 against 1: same draws up to
+                                       summation order */
     int32_t use_graph;              /* 1: replay the sweep as a captured hipGraph (default: stream launches) */
     int32_t chain_groups;           /* chains split over this many streams (0 or 1: one stream) */
     int32_t disable_mask;           /* bit 0: HMC update, bits 1..4: S->E move, E->I move, S->E occult, E->I

@@ -33,7 +33,7 @@ def oracle_constants(cov, init):
 
 
 def build_case(name, seed=20210101, alpha_t_sd=0.0):
-    """name in synth.WORKLOADS, 'micro_MxT' or 'slow_MxT' -> dict(cov, events, init, u, k).
+    """name in synth.WORKLOADS, 'micro_MxT', 'slow_MxT' or 'slower_MxT' -> dict(cov, events, init, u, k).
 
     'slow_MxT': populations 40 times larger and a reproduction number just above one, so that the epidemic is
     still running on the last day of a series of 400+ days (a 'micro' epidemic burns out after ~130 days and
@@ -46,10 +46,10 @@ def build_case(name, seed=20210101, alpha_t_sd=0.0):
         M, T = (int(x) for x in name.split("_")[1].split("x"))
         cov = small_covariates(M, T, seed)
         params = dict(alpha_0=-0.5)
-        if kind == "slow":
+        if kind in ("slow", "slower"):
             import dataclasses
-            cov = dataclasses.replace(cov, N=cov.N * 40.0)
-            params = dict(alpha_0=-1.45)
+            cov = dataclasses.replace(cov, N=cov.N * (40.0 if kind == "slow" else 400.0))
+            params = dict(alpha_0=-1.45 if kind == "slow" else -1.5)      # "slower": still running after 800 days
     events, init, truth = synth.simulate_epidemic(cov, seed, alpha_t_sd=alpha_t_sd, params=params)
     theta = synth.pack_params(truth, cov.M, cov.T)
     u = synth.unconstrain(theta)

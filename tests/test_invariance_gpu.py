@@ -99,8 +99,8 @@ def test_event_kernels_preserve_the_joint_distribution_of_simulated_epidemics(ap
 @pytest.mark.parametrize("moves", ["paired", "split"])
 @pytest.mark.parametrize("kernel", ("move/S->E", "move/E->I", "all"))
 def test_event_kernels_preserve_the_joint_distribution_over_a_long_series(api, kernel, moves):
-    """The same joint test on 3 LADs x 400 days, where the series is longer than the 384 days the wave-level
-    proposals cover and the block form (k_move_pair<false> / k_move_pa2<false>) runs: a slow trickle of single
+    """The same joint test on 3 LADs x 400 days, a series longer than the 384 days of the headline size's
+    proposal kernels (here k_move_pair<12> / k_move_pa2<12>: a row is 12 registers per lane): a slow trickle of single
     events that is still going on the last day, updates that reach across the day-chunk boundaries (dmax = 84),
     the occult window [379, 400) straddling day 384."""
     SeirModel, ChainSampler = api

@@ -128,7 +128,7 @@ _ORACLE_CACHE = {}
 
 @pytest.mark.parametrize("moves", ["paired", "split", "paired-nopre", "paired+single"])
 @pytest.mark.parametrize("name,cfg,seed,eps,n", [
-    # T > 384: the block form of the proposals (k_move_pair<false> / k_move_pa2<false>), one row and many
+    # T > 384: the 12-chunk instance of the proposal kernels (k_move_pair<12> / k_move_pa2<12>), few rows and many
     ("slow_3x400", CFG_REF, 11, 3e-5, 5),
     ("slow_70x400", CFG_SMALL, 12, 3e-5, 3),
     # T > 512: two day passes of the single-workgroup HMC kernels (k_hmc_step<*, 2, *>), 9 day chunks (rolled chunk loops)
@@ -137,19 +137,22 @@ _ORACLE_CACHE = {}
     ("slow_520x70", CFG_SMALL, 14, 3e-5, 3),
     # both, and 12 day chunks as at SYN-2048 x 730
     ("slow_530x730", CFG_REF, 15, 3e-6, 2),
+    # T > 768: the 16-chunk instance of the proposal kernels
+    ("slower_4x800", CFG_REF, 16, 3e-5, 5),
 ])
 def test_long_series_and_wide_kernel_forms_match_oracle(api, name, cfg, seed, eps, n, moves):
-    """Everything BASELINE's largest configuration (SYN-2048 x 730) runs and the smaller cases do not: the block
-    form of the event-update proposals (series longer than 384 days) and the multi-pass instances of the
-    single-workgroup HMC kernels (T > 512, M > 512), draw by draw against the oracle in every launch form.  The
-    'slow' epidemics are still running on the last day, so every day chunk holds events."""
+    """Everything BASELINE's largest configuration (SYN-2048 x 730) runs and the smaller cases do not: the
+    instances of the event-update kernels for series longer than 384 and 768 days (a row of the proposing wave is 12
+    or 16 registers per lane instead of 6) and the multi-pass instances of the single-workgroup HMC kernels
+    (T > 512, M > 512), draw by draw against the oracle in every launch form.  The 'slow' epidemics are still
+    running on the last day, so every day chunk holds events."""
     form = dict(moves=moves.split("+")[0], hmc="single" if moves.endswith("+single") else "chunk")
     SeirModel, ChainSampler = api
     case = H.build_case(name, seed, alpha_t_sd=0.005)
     B = 2
     u, ev = _start(case, B, seed, scale=0.01)
     T = case["k"].T
-    assert case["events"][:, T - 16:, :2].sum() > 0 and case["events"][:, 384:, :2].sum() > 0 or T < 384
+    assert case["events"][:, T - 16:, :2].sum() > 0 and (T < 384 or case["events"][:, 384:, :2].sum() > 0)
     if name not in _ORACLE_CACHE:                       # the same oracle trace serves the four launch forms
         oracles = []
         for b in range(B):
@@ -167,9 +170,9 @@ def test_long_series_and_wide_kernel_forms_match_oracle(api, name, cfg, seed, ep
             assert tr.hmc["is_accepted"].any()
             assert any(tr.moves[k]["is_accepted"].any() for k in tr.moves)
     if T > 384:
-        # the proposals did reach the days beyond the wave form's range
+        # the proposals did reach the last day chunks
         days = np.concatenate([tr.moves[k]["proposed_delta"][..., 1, :].ravel() for k in tr.moves])
-        assert (days >= 384).any()
+        assert (days >= 384).any() and (T < 768 or (days >= 768).any())
 
 
 def test_sampler_matches_oracle_draw_by_draw_at_uk380(api):
