@@ -61,7 +61,7 @@ class SeirSimDesc(ctypes.Structure):
 
 
 ABI_VERSION = 2               # SEIR_ABI_VERSION
-OPT_DEBUG_SKEW, OPT_XCD_AFFINITY, OPT_GEMM_F32, OPT_EVAL_FORM, OPT_LEAP_NST = 0, 1, 2, 3, 4
+OPT_DEBUG_SKEW, OPT_XCD_AFFINITY, OPT_GEMM_F32, OPT_EVAL_FORM = 0, 1, 2, 3
 MMAX = 4                      # SEIR_MMAX
 MOVE_TRACE = 2 + 4 * MMAX     # SEIR_MOVE_TRACE
 

@@ -792,12 +792,124 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
 // wait(): called once, after every load that does not depend on this launch's partial sums has been issued and
 // before the first one that does (k_se_chunk: the spin on the chain's tile counter goes there, so those loads and
 // the wait overlap); a no-op in k_hmc_chunk.
+// role_gather (k_leap): the loads of a chunk role that wait for the step's tiles, shared by the FOUR waves of the role's
+// workgroup.  A load past the L1 (what a role must use for anything another workgroup of the launch wrote) is not pipelined:
+// one wave gets them back ~47 ns apart whatever it has in flight (timeline: 24 column-sum rows 1.40 us, 12 rows 0.84, 6 rows
+// 0.56), and a T-chunk has 36 of them, an M-chunk of UK-380 51 -- most of the 2.9 us a role took.  The three waves that used
+// to retire at once now fetch a quarter each and leave what wave 0 needs in LDS, already summed where the order of k_hmc_chunk's
+// additions allows it: bit-identical to the other forms.
+//   T-chunk: wave w accumulates the column sums of row tiles w, w+4, w+8 ... (k_hmc_chunk's accumulator c_w) and fetches the
+//            tile scalars of day chunks w, w+4, w+8.
+//   M-chunk: wave 1 the row partials of the chunk's own rows, wave 2 the per-tile psi partials (and row scalars), and for the
+//            small-M form (the M-chunks sum the row partials of ALL rows themselves) rows kk of a lane by waves 0,0,1,2,3,3,1,2.
+template <int NC> struct RoleGather {                           // offsets (doubles) into the role's LDS block
+    static constexpr int C = 0, BS = 4 * WAVE, AS = BS + NC * WAVE;                              // T-chunk
+    static constexpr int X = 0, PS = NC * WAVE, RL = PS + WAVE, RS = RL + WAVE, ACC = RS + WAVE;   // M-chunk
+    static constexpr int SIZE = (4 + 2 * NC) * WAVE > (NC + 3 + 8) * WAVE ? (4 + 2 * NC) * WAVE : (NC + 3 + 8) * WAVE;
+};
+__device__ __forceinline__ int role_gather_row_wave(int kk) { return kk < 2 ? 0 : kk == 2 || kk == 6 ? 1 : kk == 3 || kk == 7 ? 2 : 3; }
+template <int NTC>
+__device__ __forceinline__ void role_gather(const Dims &d, const Work &w, int b, int bx, int wv, int lane, double *g) {
+    auto LDP = [](const double *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    constexpr int NC = NTC > 0 ? NTC : CT_MAXC;
+    using G = RoleGather<NC>;
+    const int nmt = d.nmt, ntc = NTC > 0 ? NTC : d.ntc, ntile = nmt * ntc, M = d.M;
+    const double *TS = w.TS + (size_t)b * ntile * 4;
+    if (bx < ntc) {
+        const int t = bx * WAVE + lane;
+        const double *kp = w.Kpart + (size_t)b * nmt * d.Tp + t;
+        double cw = 0.0;
+        for (int j0 = 0; j0 < nmt; j0 += 24) {
+            double x[6];
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {
+                const int j = j0 + wv + 4 * jj;
+                const double v_ = LDP(kp + (size_t)min(j, nmt - 1) * d.Tp);
+                x[jj] = j < nmt ? v_ : 0.0;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) cw += x[jj];
+        }
+        double b_[(NC + 3) / 4], a_[(NC + 3) / 4];
+#pragma unroll
+        for (int i = 0; i < (NC + 3) / 4; ++i) {
+            const int cc = wv + 4 * i;
+            const double *tp_ = TS + ((size_t)min(lane, nmt - 1) * ntc + min(cc, ntc - 1)) * 4;
+            b_[i] = LDP(tp_); a_[i] = LDP(tp_ + 1);
+        }
+        g[G::C + wv * WAVE + lane] = cw;
+#pragma unroll
+        for (int i = 0; i < (NC + 3) / 4; ++i) {
+            const int cc = wv + 4 * i;
+            const bool on = cc < ntc && lane < nmt;
+            if (cc < NC) { g[G::BS + cc * WAVE + lane] = on ? b_[i] : 0.0; g[G::AS + cc * WAVE + lane] = on ? a_[i] : 0.0; }
+        }
+    } else {
+        const int ci = bx - ntc, m = ci * WAVE + lane;
+        const bool own = m < M;
+        const bool rows_here = d.chunked == 1;
+        if (wv == 1) {
+            const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (own ? m : 0);
+            double x[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { const double v_ = LDP(rp + (size_t)min(j, ntc - 1) * d.Mp); x[j] = (own && j < ntc) ? v_ : 0.0; }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) g[G::X + j * WAVE + lane] = x[j];
+        }
+        if (wv == 2) {
+            double ps = 0.0, rl = 0.0, rs = 0.0;
+            for (int i0 = lane; i0 < ntile; i0 += 4 * WAVE) {
+                double x[4], y[4], z[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j * WAVE;
+                    const bool on = i < ntile;
+                    const int ic = on ? i : 0;
+                    const double xv = LDP(w.Ppart + (size_t)b * ntile + ic);
+                    x[j] = on ? xv : 0.0;
+                    y[j] = 0.0; z[j] = 0.0;
+                    if (!rows_here) {                            // uniform
+                        const double yv = LDP(TS + (size_t)ic * 4 + 2), zv = LDP(TS + (size_t)ic * 4 + 3);
+                        y[j] = on ? yv : 0.0; z[j] = on ? zv : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ps += x[j]; rl += y[j]; rs += z[j]; }
+            }
+            g[G::PS + lane] = ps; g[G::RL + lane] = rl; g[G::RS + lane] = rs;
+        }
+        if (rows_here) {
+            const int nrow = (M + WAVE - 1) / WAVE;              // uniform, <= 8 (Mp <= 512)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if (role_gather_row_wave(kk) != wv || kk >= nrow) continue;
+                const int mm = lane + kk * WAVE;
+                const bool on = mm < M;
+                const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (on ? mm : 0);
+                double x[NC];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) { const double v_ = LDP(rp + (size_t)(j < ntc ? j : 0) * d.Mp); x[j] = (on && j < ntc) ? v_ : 0.0; }
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc += x[j];
+                g[G::ACC + kk * WAVE + lane] = acc;
+            }
+        }
+    }
+}
+
 // PERS (k_leap: all inner steps in ONE launch): what the previous step's roles wrote -- position and momentum, the
 // global parameters, the chunk sums, the spatial effects -- was written by workgroups of this same launch too, so those
 // are read past the L1 as well (the caller makes sure every role of the previous step has finished).
 template <int NTC, bool COH, bool PERS = false, typename Wait>
 __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
-                                               const Chains &ch, int par, int bx, int b, Wait wait, int lane_in = -1) {
+                                               const Chains &ch, int par, int bx, int b, Wait wait, int lane_in = -1,
+                                               unsigned long long *probe = nullptr, double *gbuf = nullptr) {
+#ifdef LEAP_STAMPS
+#define CPROBE(k) do { asm volatile("s_nop 0" ::: "memory"); if (probe && threadIdx.x == 0) probe[(k) < 8 ? (k) : 2 * 128 + (k) - 8] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CPROBE(k) do {} while (0)
+#endif
     __shared__ double2 ltab[LOGTAB_N];
     auto LDP = [](const double *p_) {
         return COH ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_;
@@ -845,8 +957,12 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         // The I->R part of the step needs nothing of this step's tiles -- gamma0 and gamma1 move by the chunk parts the
         // previous step left (Work::CG) -- so all of it (two wave sums, the new rates, the series, two more wave sums: half of
         // the role's dependent operations) runs BEFORE the wait, under the tile phase.  Same operations, same results.
-        lds_barrier();                                     // ltab (single wave: orders the LDS writes)
+        CPROBE(10);                                         // entry loads issued
+        if (PERS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the workgroup's other waves are alive there: no s_barrier)
+        else lds_barrier();                                // ltab (single wave: orders the LDS writes)
         const double gg0 = wave_sum(cg0_l), gg1 = wave_sum(cg1_l);
+        if (probe) { asm volatile("" :: "v"(gg0), "v"(gg1)); }
+        CPROBE(11);                                         // entry loads back, two wave sums
         const double pg0n = pg0 + eps * (gg0 - g0 / 1.0e4), g0n = g0 + eps * vg0 * pg0n;
         const double pg1n = pg1 + eps * (gg1 - g1 / 1.0e4), g1n = g1 + eps * vg1 * pg1n;
         double ng0p = 0.0, ng1p = 0.0, rnew = 0.0;
@@ -860,29 +976,45 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             ng1p = grr * rnew * wd_t;
         }
         const double ng0s = wave_sum(ng0p), ng1s = wave_sum(ng1p);
+        if (probe) { asm volatile("" :: "v"(ng0s), "v"(ng1s)); }
+        CPROBE(12);                                         // I->R part done
         wait();
         // ---- from here on: this step's partial sums
-        // column sums of this chunk
         double col = 0.0;
+        double bs[NC], as[NC];
+        if (PERS) {
+            // the four waves of the workgroup fetch a quarter each (role_gather); wave 0 is this one
+            using G = RoleGather<NC>;
+            role_gather<NTC>(d, w, b, bx, 0, lane, gbuf);
+            lds_barrier();
+            col = (gbuf[G::C + lane] + gbuf[G::C + WAVE + lane]) + (gbuf[G::C + 2 * WAVE + lane] + gbuf[G::C + 3 * WAVE + lane]);
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) { bs[cc] = gbuf[G::BS + cc * WAVE + lane]; as[cc] = gbuf[G::AS + cc * WAVE + lane]; }
+            if (probe) { asm volatile("" :: "v"(col)); }
+            CPROBE(8);                                          // column sums in
+        } else {
+        // column sums of this chunk
         {
             const double *kp = w.Kpart + (size_t)b * nmt * d.Tp + t;
             double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
             // twelve loads in flight at a time (twenty-four cost 24 more registers, and the kernel that carries this role
             // next to the gradient tile has to stay at five waves per SIMD); same order of additions as one batch of 24
-            for (int j0 = 0; j0 < nmt; j0 += 12) {
-                double x[12];
+            constexpr int KB = 12;
+            for (int j0 = 0; j0 < nmt; j0 += KB) {
+                double x[KB];
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {             // clamped index + select: a conditional L1-bypassing load is a branch
+                for (int j = 0; j < KB; ++j) {             // clamped index + select: a conditional L1-bypassing load is a branch
                     const double v_ = LDP(kp + (size_t)min(j0 + j, nmt - 1) * d.Tp);
                     x[j] = j0 + j < nmt ? v_ : 0.0;
                 }
 #pragma unroll
-                for (int j = 0; j < 12; j += 4) { c0 += x[j]; c1 += x[j + 1]; c2 += x[j + 2]; c3 += x[j + 3]; }
+                for (int j = 0; j < KB; j += 4) { c0 += x[j]; c1 += x[j + 1]; c2 += x[j + 2]; c3 += x[j + 3]; }
             }
             col = (c0 + c1) + (c2 + c3);
         }
+        if (probe) { asm volatile("" :: "v"(col)); }
+        CPROBE(8);                                          // column sums in
         // tile scalars of row tile `lane` (and lane+64, ... when there are more)
-        double bs[NC], as[NC];
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) {
             const bool on = cc < ntc && lane < nmt;
@@ -903,6 +1035,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                 for (int cc = c0; cc < c0 + 3 && cc < NC; ++cc) asm volatile("" : "+v"(bs[cc]), "+v"(as[cc]));   // the sums, here
             }
         }
+        }
         // Everything that couples the chunks is linear in the tile scalars, so each lane forms its
         // row tile's share and three wave sums finish the job:
         //   later = sum_{c' > ci} B(c'),  allB = sum B,
@@ -920,7 +1053,11 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             lat += bs[cc];
         }
         p_pre = eps * eps * p_pre + (lane < ci ? cta_l + eps * (ctvp_l - eps * PREC * ctva_l) : 0.0);
+        if (probe) { asm volatile("" :: "v"(col), "v"(p_pre)); }
+        CPROBE(5);                                          // loads back
         const double later = wave_sum(p_later), allB = wave_sum(p_all), pre = wave_sum(p_pre);
+        if (probe) { asm volatile("" :: "v"(later), "v"(allB), "v"(pre)); }
+        CPROBE(6);                                          // three wave sums
         // this chunk's entries
         const double insuf = wave_incl_suffix_scan(col, lane);
         const double g = own ? (insuf + later) - alpha * PREC : 0.0;
@@ -928,13 +1065,16 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const double an = own ? alpha + eps * v * pn : 0.0;
         const double pa0n = pa0 + eps * (allB - a0 / 100.0), a0n = a0 + eps * va0 * pa0n;
         const double a_new = a0n + pre + wave_incl_scan(an, lane);
+        if (probe) { asm volatile("" :: "v"(a_new)); }
+        CPROBE(7);                                          // two scans
+        // (the chunk sums for the next step before the exponential: independent of it, so the two chains overlap)
+        const double ca = wave_sum(an), cvp = wave_sum(v * pn), cva = wave_sum(v * an);
         if (own) { q[oT + t] = an; p[oT + t] = pn; }
         if (t < T) {
             w.acur[(size_t)b * d.Tp + t] = a_new;
             w.ea[(size_t)b * d.Tp + t] = exp(a_new);
             w.rir[(size_t)b * d.Tp + t] = rnew;            // read by nobody in this launch
         }
-        const double ca = wave_sum(an), cvp = wave_sum(v * pn), cva = wave_sum(v * an);
         if (lane == 0) {
             double *ctw = w.CT + (((size_t)b * 2 + (par ^ 1)) * CT_MAXC + ci) * 4;
             ctw[0] = ca; ctw[1] = cvp; ctw[2] = cva;
@@ -978,9 +1118,41 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         }
         const bool rows_here = d.chunked == 1;             // small M: sum_m l_m R_m, sum_m s_m R_m from the row partials
         constexpr int RPL = 8;                             // Mp <= 512: rows lane, lane+64, ...
+        // (k_leap: the rows' l_m and s_m -- the previous step's -- before the wait; what waits for the tiles comes from the
+        // workgroup's four waves through LDS, role_gather)
+        double lxp[PERS ? RPL : 1], sxp[PERS ? RPL : 1];
+        if (PERS && rows_here) {
+#pragma unroll
+            for (int kk = 0; kk < RPL; ++kk) {
+                const int mm = lane + kk * WAVE;
+                const bool on = mm < M;
+                const int mc = on ? mm : 0;
+                const double lv_ = c.la[mc], sv_ = LDQ(spr + mc);
+                lxp[kk] = on ? lv_ : 0.0;
+                sxp[kk] = on ? sv_ : 0.0;
+            }
+        }
         wait();
         // ---- from here on: this step's partial sums
         double R = 0.0;
+        double ps = 0.0, rl = 0.0, rs = 0.0;
+        if (PERS) {
+            using G = RoleGather<NC>;
+            role_gather<NTC>(d, w, b, bx, 0, lane, gbuf);
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < NC; ++j) R += gbuf[G::X + j * WAVE + lane];
+            ps = gbuf[G::PS + lane]; rl = gbuf[G::RL + lane]; rs = gbuf[G::RS + lane];
+            if (rows_here) {
+                const int nrow = (M + WAVE - 1) / WAVE;      // uniform
+#pragma unroll
+                for (int kk = 0; kk < RPL; ++kk)
+                    if (kk < nrow) {
+                        const double acc = gbuf[G::ACC + kk * WAVE + lane];
+                        rl = fma(lxp[kk], acc, rl); rs = fma(sxp[kk], acc, rs);
+                    }
+            }
+        } else {
         {
             const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (own ? m : 0);
             double x[NC];
@@ -989,7 +1161,6 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
 #pragma unroll
             for (int j = 0; j < NC; ++j) R += x[j];
         }
-        double ps = 0.0, rl = 0.0, rs = 0.0;
         for (int i0 = lane; i0 < ntile; i0 += 4 * WAVE) {
             double x[4], y[4], z[4];
 #pragma unroll
@@ -1008,11 +1179,12 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             // registers across the wait (sixteen values per lane were: with them this role needed 113 VGPRs, and the
             // gradient launch that carries it, k_se_chunk, stays at five waves per SIMD only up to 96)
             const int nrow = (M + WAVE - 1) / WAVE;          // uniform
-            for (int k0 = 0; k0 < RPL; k0 += 3) {
+            constexpr int RB = 3;
+            for (int k0 = 0; k0 < RPL; k0 += RB) {
                 if (k0 >= nrow) break;
-                double lx[3], sx[3], x[3][NC];
+                double lx[RB], sx[RB], x[RB][NC];
 #pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
+                for (int kk = 0; kk < RB; ++kk) {
                     const int mm = lane + (k0 + kk) * WAVE;
                     const bool on = k0 + kk < RPL && mm < M;
                     const int mc = on ? mm : 0;
@@ -1027,13 +1199,14 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                     }
                 }
 #pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
+                for (int kk = 0; kk < RB; ++kk) {
                     double acc = 0.0;
 #pragma unroll
                     for (int j = 0; j < NC; ++j) acc += x[kk][j];
                     rl = fma(lx[kk], acc, rl); rs = fma(sx[kk], acc, rs);
                 }
             }
+        }
         }
         ps = wave_sum(ps); rl = wave_sum(rl); rs = wave_sum(rs);
         const double g = own ? sig * R - Qs : 0.0;
@@ -1433,13 +1606,16 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         leap_tile<TSM, NST>(d, c, w, s, ch, tile % d.ntc, tile / d.ntc, bz, par0, nsteps, step_base);
         return;
     }
-    if (threadIdx.x >= WAVE) return;                   // a role is one wave
+    // a role: wave 0 runs it, the workgroup's other three waves share its loads of the tiles' partial sums (role_gather)
+    __shared__ double gbuf[RoleGather<(NTC > 0 ? NTC : CT_MAXC)>::SIZE];
     const int L = (int)blockIdx.x - n_tiles;
     const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
     if (d.nlive > 0 && bz >= d.nlive) return;
     debug_skew(d);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane_w = (int)(threadIdx.x & 63);
     const int nsh = min(LEAP_NSH, nwg);
-    const unsigned long long *flag1 = LEAP_FLAG1(b, (int)threadIdx.x < nsh ? (int)threadIdx.x : 0);   // lane k < nsh looks at shard k
+    const unsigned long long *flag1 = LEAP_FLAG1(b, lane_w < nsh ? lane_w : 0);   // lane k < nsh looks at shard k
     unsigned long long *cnt2 = LEAP_CNT2(b);
     const unsigned long long *flag2 = LEAP_FLAG2(b, role & (LEAP_NSH - 1));
     unsigned *late = ch.late + ch.late_fatal + b;
@@ -1448,22 +1624,37 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         // (variances, V(t), the I->R statistics, CAR rows ...) out of the loop and spills 500+ bytes per lane to hold them
         asm volatile("" ::: "memory");
         const int par = par0 ^ (it & 1);
-        // what the roles of the previous step wrote (chunk sums, global parameters, spatial effects, q and p)
-        if (it > 0) leap_wait(flag2, step_base + (unsigned long long)it, late);
-        RPROBE(0);                                               // the previous step's roles are done
         const unsigned long long stepno = step_base + (unsigned long long)(it + 1);
-        int lane_op = (int)threadIdx.x;
+        int lane_op = lane_w;
         asm volatile("" : "+v"(lane_op));
-        hmc_chunk_role<NTC, true, true>(d, c, w, s, ch, par, role, b, [&] {
+        auto wait_tiles = [&] {
             if (nwg >= 32) __builtin_amdgcn_s_sleep(LEAP_BACKOFF);
             int spins = 0;                                       // every shard's tiles are in: all of (up to) eight flags show the step
             while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(flag1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stepno) != 0ull) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { if (threadIdx.x == 0) *late += 1; break; }
+                if (++spins > (1 << 22)) { if (lane_w == 0) *late += 1; break; }
             }
+        };
+        if (wv != 0) {
+            wait_tiles();
+            role_gather<NTC>(d, w, b, role, wv, lane_op, gbuf);
+            lds_barrier();                                       // wave 0 is at its own, inside the role
+            continue;
+        }
+        // what the roles of the previous step wrote (chunk sums, global parameters, spatial effects, q and p)
+        if (it > 0) leap_wait(flag2, step_base + (unsigned long long)it, late);
+        RPROBE(0);                                               // the previous step's roles are done
+        hmc_chunk_role<NTC, true, true>(d, c, w, s, ch, par, role, b, [&] {
+            wait_tiles();
             if (threadIdx.x == 0) { LSTAMP_MIN(4); LSTAMP_MAX(5); }
             RPROBE(1);                                           // the step's tiles are in
-        }, lane_op);
+        }, lane_op,
+#ifdef LEAP_STAMPS
+        (b == 0 && role == 0) ? ch.leap_st + ((size_t)1 * 16 + (it & 15)) * 8 : nullptr,
+#else
+        nullptr,
+#endif
+        gbuf);
         RPROBE(2);                                               // stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this role's stores are in the XCD's L2
         RPROBE(3);

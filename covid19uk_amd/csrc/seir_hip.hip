@@ -54,7 +54,6 @@ struct seir_ctx {
     bool prepared = false;
     int opt_skew = 0, opt_affinity = 3;     // seir_set_option
     int opt_gemm_f32 = 0;
-    int opt_leap_nst = 0;          // SEIR_OPT_LEAP_NST: gradient tiles per workgroup of k_leap (0 = the largest that fits)
     int opt_eval_form = 0;            // 0 auto (one launch where a chain's blocks share an XCD, else three), 1 four launches, 2 three
     int xcd_local = -1;               // -1 not probed yet; 1: blocks with the same id mod 8 share an XCD, eight different ones
     unsigned long long *eval_cnt = nullptr;   // [8][EVC_STRIDE] k_eval_all's counters
@@ -316,10 +315,6 @@ extern "C" int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value) {
         case SEIR_OPT_EVAL_FORM:
             if (value < 0 || value > 2) return fail(SEIR_ERR_INVALID, "eval form is 0 (auto), 1 (four launches) or 2 (three launches)");
             ctx->opt_eval_form = value;
-            return 0;
-        case SEIR_OPT_LEAP_NST:
-            if (value != 0 && value != 1 && value != 2) return fail(SEIR_ERR_INVALID, "leap_nst is 0 (auto), 1 or 2");
-            ctx->opt_leap_nst = value;
             return 0;
         case SEIR_OPT_GEMM_F32: {
             if (value < 0 || value > 1) return fail(SEIR_ERR_INVALID, "gemm_f32 is 0 or 1");
@@ -1367,7 +1362,7 @@ static void group_range(const seir_sampler *s, int g, int &b0, int &nb) {
 
 // the instance of the persistent leapfrog kernel for (tile-scalar mode, day chunks, gradient tiles per workgroup)
 static const void *leap_fn(int ts_mode, int ntc, int nst) {
-#define LEAP_ROW(TSM_, NTC_) (nst == 2 ? (const void *)k_leap<TSM_, NTC_, 2> : (const void *)k_leap<TSM_, NTC_, 1>)
+#define LEAP_ROW(TSM_, NTC_) ((void)nst, (const void *)k_leap<TSM_, NTC_, 2>)
     if (ts_mode == 1) return ntc == 1 ? LEAP_ROW(1, 1) : ntc == 6 ? LEAP_ROW(1, 6) : LEAP_ROW(1, 12);
     return ntc == 1 ? LEAP_ROW(2, 1) : ntc == 6 ? LEAP_ROW(2, 6) : LEAP_ROW(2, 12);
 #undef LEAP_ROW
@@ -1414,13 +1409,12 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         // workgroup of that launch can be resident at once -- its tiles wait for the roles
         bool leap = false;
         int leap_nst = 1;
-        if (tail && s->hmc_leap && c.L >= 3) {
-            // gradient tiles per workgroup: 2 or 1 (or the one asked for: SEIR_OPT_LEAP_NST), whose launch fits the chip at
-            // once (four were measured too: 13.2 us per step against 10.4 -- 67 KB of LDS and two waves per SIMD)
+        if (tail && s->hmc_leap && c.L >= 3 && d0.nmt <= WAVE) {     // (role_gather: a lane per row tile)
+            // two gradient tiles per workgroup (one: 96 VGPRs for five waves per SIMD, 176 B of scratch per lane, 18 us per
+            // step; four: 67 KB of LDS, two waves per SIMD, 13.2 us; two: 10.1 us), if that launch fits the chip at once
             const int ti = ts_mode - 1, ni = d0.ntc == 1 ? 0 : d0.ntc == 6 ? 1 : 2;
-            for (int k = 1; k >= 0 && !leap; --k) {
+            for (int k = 1; k >= 1 && !leap; --k) {
                 const int nst = 1 << k;
-                if (ctx->opt_leap_nst != 0 && ctx->opt_leap_nst != nst) continue;
                 if (d0.nmt % nst != 0) continue;
                 if (s->leap_occ[ti][ni][k] < 0) {
                     const void *fn = leap_fn(ts_mode, d0.ntc, nst);

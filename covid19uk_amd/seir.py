@@ -141,14 +141,12 @@ class SeirModel:
     def sync(self):
         _lib.check(self._lib.seir_sync(self._ctx))
 
-    def set_option(self, debug_skew=None, xcd_affinity=None, gemm_f32=None, eval_form=None, leap_nst=None):
+    def set_option(self, debug_skew=None, xcd_affinity=None, gemm_f32=None, eval_form=None):
         """Launch options of the context (seir_set_option): the workgroup-timing test hook, the
         chain <-> XCD block mapping and the launch form of `log_prob_dev` ("fused" -- one launch for 8 or 16 chains where the GPU
         allows it, else three -- | "three-launch" | "four-launch"; none of
         them changes a result beyond summation order), and `gemm_f32`: the mobility contraction
         with fp32 operands on the fp32 matrix instruction (BASELINE config 5; ~1e-8 relative on the log-prob)."""
-        if leap_nst is not None:       # gradient tiles per workgroup of the persistent leapfrog kernel (0 = auto)
-            _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_LEAP_NST, int(leap_nst)))
         if eval_form is not None:
             form = {"fused": 0, "four-launch": 1, "three-launch": 2}[eval_form]
             _lib.check(self._lib.seir_set_option(self._ctx, _lib.OPT_EVAL_FORM, form))

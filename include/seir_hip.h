@@ -117,9 +117,6 @@ void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context
  *                            config 5).  THIS ONE CHANGES RESULTS: F carries ~1e-7 relative error, the log-prob
  *                            ~1e-8 -- outside the 1e-9 the fp64 path is held to; off by default.  Needs
  *                            ceil64(M) and ceil64(T) to be multiples of 128.
- *   SEIR_OPT_LEAP_NST        gradient tiles (16 rows x 64 days) per workgroup of the persistent leapfrog kernel (speed only, same
- *                            bits): 0 (default) = 2 where that launch fits the chip at once, else 1; 1, 2 = that one or, where it
- *                            does not fit, one launch per step
  *   SEIR_OPT_EVAL_FORM       launch form of seir_log_prob_dev (speed only): 0 (default) = the S->E term evaluated on the
  *                            contraction's accumulators and the row constants beside the matrix-core tiles, as ONE
  *                            launch for a batch of 8 or 16 chains (a multiple of 8 whose tile workgroups all fit the chip) on a
@@ -127,7 +124,7 @@ void *seir_stream(seir_ctx *ctx);                  /* hipStream_t of the context
  *                            over through that XCD's L2), as three launches otherwise; 1 = the four-launch form (scan, contraction, S->E tiles, reduction); 2 = always
  *                            three launches.  0 and 2 give the same bits
  * Options are read when a launch is enqueued (for a sampler using graph replay: at capture). */
-enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2, SEIR_OPT_EVAL_FORM = 3, SEIR_OPT_LEAP_NST = 4 };
+enum { SEIR_OPT_DEBUG_SKEW = 0, SEIR_OPT_XCD_AFFINITY = 1, SEIR_OPT_GEMM_F32 = 2, SEIR_OPT_EVAL_FORM = 3 };
 int seir_set_option(seir_ctx *ctx, int32_t option, int32_t value);
 
 /* Device memory helpers so that a ctypes host can keep inputs resident

@@ -14,9 +14,8 @@ ev = np.stack([case["events"]] * B)
 cfg = dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=2)
 eps = 0.02 if name == "ni11" else 1.2e-5
 out = {}
-for mode, nst in (("chunk-split", 0), ("chunk-launch", 0), ("chunk", 1), ("chunk", 2)):
+for mode, nst in (("chunk-split", 0), ("chunk-launch", 0), ("chunk", 2)):
     with SeirModel(case["cov"], case["init"], max_chains=B) as model:
-        model.set_option(leap_nst=nst)
         with ChainSampler(model, cfg, B, seed=77, trace_capacity=10, hmc=mode, disable=("move/S->E", "move/E->I", "occult/S->E", "occult/E->I")) as s:
             s.set_state(u, ev)
             s.set_kernel(step_size=eps)

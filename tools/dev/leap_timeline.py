@@ -20,7 +20,6 @@ ev = np.stack([events] * B)
 lib = _lib.load()
 lib.seir_debug_leap_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 with SeirModel(cov, init, max_chains=B) as model:
-    model.set_option(leap_nst=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     with ChainSampler(model, cfg, B, seed=1, trace_capacity=50, record_events=False) as s:
         s.set_state(u, ev); s.set_kernel(step_size=1.2e-5)
         s.run(20); model.sync()
@@ -34,7 +33,12 @@ with SeirModel(cov, init, max_chains=B) as model:
             allt = out[(B + 2) * 128:].reshape(1024, 4).copy()
         st = np.stack(reps) * 10.0                             # ns (100 MHz clock)
         tiles = st[:, B:, :15, :7]                             # [rep, tile 0 / 77, step, stamp]
-        roles = st[:, 1:3, :15, :5]                            # [rep, T-chunk 0 / M-chunk 0, step, stamp]
+        roles = st[:, 1:3, :15, :5]
+        inner = st[:, 1, 1:14, 5:8] - st[:, B, 1:14, :1]        # T-chunk 0: loads back, wave sums, scans (ns after tile 0 passed the wait)
+        print("T-chunk 0 inside: loads back %.0f, three wave sums %.0f, two scans %.0f" % tuple(np.median(inner[..., k]) for k in range(3)))
+        more = st[:, 3, 1:14, :5] - st[:, B, 1:14, :1]
+        print("T-chunk 0 inside: column sums in %.0f; before the wait: entry loads issued %.0f, back + two wave sums %.0f, I->R part done %.0f" % (
+            np.median(more[..., 0]), np.median(more[..., 2]), np.median(more[..., 3]), np.median(more[..., 4])))                            # [rep, T-chunk 0 / M-chunk 0, step, stamp]
         period = np.median(tiles[:, 0, 2:15, 0] - tiles[:, 0, 1:14, 0])
         print(f"step period (tile 0 past its wait, step to step): median {period:.0f} ns; whole launch ~{period * 15 / 1e3:.1f} us")
         pn = ["past the wait", "tables in LDS", "cells done", "past middle barrier", "reductions issued", "stores acknowledged", "counted in"]

@@ -14,7 +14,6 @@ def main():
     ap.add_argument("--hmc", default="chunk")
     ap.add_argument("--moves", default="paired")
     ap.add_argument("--graph", action="store_true", help="replay the sweep as a hipGraph")
-    ap.add_argument("--leap-nst", type=int, default=0, help="gradient tiles per workgroup of k_leap (0 = auto)")
     args = ap.parse_args()
     import __graft_entry__ as entry
     entry.build()
@@ -33,7 +32,6 @@ def main():
         if g > B:
             continue
         with SeirModel(cov, init, max_chains=B) as model:
-            model.set_option(leap_nst=args.leap_nst)
             with ChainSampler(model, cfg, B, seed=1, trace_capacity=args.sweeps, chain_groups=g, hmc=args.hmc, moves=args.moves, use_graph=args.graph) as s:
                 s.set_state(u, ev)
                 s.set_kernel(step_size=1.2e-5)
