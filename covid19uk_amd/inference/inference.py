@@ -82,12 +82,28 @@ def write_inference_data(path, cov: model_spec.Covariates, cases, dates=None):
         f.write("/observations/time", np.array(dates, dtype=f"S{n}"))
 
 
+def read_location_names(path):
+    """The `location` coordinate of the input file (LAD codes; covid19uk/data/assemble.py writes it with the
+    `constant_data` group), or None when the file carries none."""
+    if str(path).endswith(".npz"):
+        return None
+    with hdf5io.File(path, "r") as f:
+        for name in ("/constant_data/location", "/observations/location"):
+            if f.exists(name):
+                v = f.read(name)
+                if v.dtype.kind in "SO":
+                    return [x.decode() if isinstance(x, bytes) else str(x) for x in v.reshape(-1)]
+                return [str(int(x)) for x in v.reshape(-1)]
+    return None
+
+
 # ---------------------------------------------------------------------------
 # posterior.hd5 (gemlib `Posterior`: samples/<key>, results/<nested/keys>)
 # ---------------------------------------------------------------------------
 class Posterior:
     """HDF5 sink with the dataset layout of inference.py:285-300 / :245-282 / :588-592.
-    `is_accepted` is stored as int8 0/1 (h5py stores numpy bool as an int8 enum)."""
+    `is_accepted` is a bool dataset the way h5py stores one (gemlib's Posterior writes numpy bools through h5py):
+    the int8 enum {FALSE = 0, TRUE = 1}."""
 
     def __init__(self, filename, M, T, mmax, num_samples, burst=100):
         self.filename = filename
@@ -98,12 +114,12 @@ class Posterior:
             "samples/spatial_effect": (M,), "samples/seir": (M, T, 3),
             "results/hmc/is_accepted": (), "results/hmc/target_log_prob": (), "results/hmc/step_size": (),
         }
-        self.dtypes = {"results/hmc/is_accepted": np.int8}
+        self.dtypes = {"results/hmc/is_accepted": np.bool_}
         for key in MOVE_KEYS:
             self.shapes[f"results/{key}/is_accepted"] = ()
             self.shapes[f"results/{key}/target_log_prob"] = ()
             self.shapes[f"results/{key}/proposed_delta"] = (4, mmax)
-            self.dtypes[f"results/{key}/is_accepted"] = np.int8
+            self.dtypes[f"results/{key}/is_accepted"] = np.bool_
         self.num_samples = int(num_samples)
         self._scratch = {}
         if self.use_h5:
@@ -304,7 +320,20 @@ def dispersed_start(P, chain_ids, scale, seed):
     return u0
 
 
-def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool_step_size=False, init_jitter=0.0):
+def trace_events_dtype(cases, choice="auto"):
+    """Width of the event counts in the device-side burst buffer: "u16" halves the buffer and the bytes that cross PCIe
+    per draw, but a count above 65535 cannot be held (the read then fails loudly, after the burst has run).  "auto" decides
+    from the data before anything runs: the latent S->E / E->I counts of a LAD-day are of the order of its observed
+    removals, so 16-bit counts are used while 16 x the largest observed count stays below the limit, int32 otherwise."""
+    if choice in ("u16", "int32"):
+        return "u16" if choice == "u16" else True
+    if choice != "auto":
+        raise ValueError(f"events dtype {choice!r}: choose auto, u16 or int32")
+    return "u16" if 16.0 * float(np.max(cases, initial=0.0)) < 65535.0 else True
+
+
+def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool_step_size=False, init_jitter=0.0,
+         events_dtype="auto"):
     """Constructs and runs the MCMC (covid19uk/inference/inference.py:473-608).
 
     Multi-GPU: launched as one process per GPU, every rank runs `num_chains` chains with
@@ -337,7 +366,8 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool
     model = SeirModel(cov, initial_state, max_chains=B, device=lay["device"])
     sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),
                            num_leapfrog_steps=hmc_kernel_kwargs_default()["num_leapfrog_steps"],
-                           trace_capacity=cap, record_events="u16", first_chain_id=lay["first_chain_id"])
+                           trace_capacity=cap, record_events=trace_events_dtype(cases, events_dtype),
+                           first_chain_id=lay["first_chain_id"])
     u0 = dispersed_start(P, [lay["first_chain_id"] + c for c in range(B)], float(init_jitter), seed)
     sampler.set_state(u0, np.stack([events] * B))
     print("Initial logpi:", sampler.log_prob(), flush=True)
@@ -380,11 +410,14 @@ def main(argv=None):
                         help="sample with the geometric mean of all chains' adapted HMC step sizes (one all_gather)")
     parser.add_argument("--init-jitter", type=float, default=0.0,
                         help="sd of the N(0, sd^2) start of chains 1.. in the unconstrained space (chain 0 starts at 0 as the reference)")
+    parser.add_argument("--events-dtype", choices=["auto", "u16", "int32"], default="auto",
+                        help="width of the event counts in the device-side burst buffer (auto: 16 bit while 16 x the largest "
+                             "observed count fits, else 32)")
     args = parser.parse_args(argv)
     with open(args.config, "r") as f:
         config = yaml.load(f, Loader=yaml.FullLoader)
     mcmc(args.data_file, args.output, config["Mcmc"], seed=args.seed, num_chains=args.chains, device=args.device,
-         pool_step_size=args.pool_step_size, init_jitter=args.init_jitter)
+         pool_step_size=args.pool_step_size, init_jitter=args.init_jitter, events_dtype=args.events_dtype)
 
 
 if __name__ == "__main__":

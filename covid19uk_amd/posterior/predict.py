@@ -16,7 +16,7 @@ import pickle as pkl
 import numpy as np
 
 from .. import hdf5io, model_spec
-from ..inference.inference import read_inference_data
+from ..inference.inference import read_inference_data, read_location_names
 from ..seir import SeirModel
 
 ALPHA_T_SCALE = 0.005          # model_spec.py:158-165
@@ -102,15 +102,16 @@ def predict(data, posterior_samples, output_file, initial_step, num_steps, out_o
     cov = model_spec.Covariates(C=cov.C, W=cov.W, N=cov.N, adjacency=cov.adjacency, weekday=weekday, area=cov.area)
     init, events = predicted_incidence(samples, initial_state, cov, initial_step, num_steps, out_of_sample,
                                        seed=seed, device=device)
+    # the `predictions` group as the reference's xarray.Dataset.to_netcdf writes it (predict.py:124-147): events on
+    # (iteration, location, time, event), initial_state on (iteration, location, state), every dimension a coordinate
+    locations = read_location_names(data) or [str(i) for i in range(events.shape[1])]
+    times = days[initial_step:] if days is not None else np.arange(initial_step, initial_step + events.shape[2])
     with hdf5io.File(output_file, "a") as f:
-        f.create_dataset("/predictions/events", events.shape, np.float64)
-        f.write("/predictions/events", events)
-        f.create_dataset("/predictions/initial_state", init.shape, np.float64)
-        f.write("/predictions/initial_state", init)
-        if days is not None:
-            t = np.array([str(x) for x in days[initial_step:]], dtype="S10")
-            f.create_dataset("/predictions/time", t.shape, "S10")
-            f.write("/predictions/time", t)
+        f.write_netcdf_group("predictions",
+                             {"iteration": np.arange(events.shape[0]), "location": locations, "time": times,
+                              "event": np.arange(events.shape[3]), "state": np.arange(init.shape[-1])},
+                             {"events": (("iteration", "location", "time", "event"), events),
+                              "initial_state": (("iteration", "location", "state"), init)})
     return init, events
 
 

@@ -10,7 +10,7 @@ import pickle as pkl
 import numpy as np
 
 from .. import hdf5io
-from ..inference.inference import read_inference_data
+from ..inference.inference import read_inference_data, read_location_names
 from ..seir import SeirModel
 
 CHUNKSIZE = 50            # reproduction_number.py:47
@@ -31,18 +31,24 @@ def calc_posterior_rit(samples, initial_state, covariates, device=0):
 
 
 def reproduction_number(input_files, output_file, device=0):
-    cov, _, _ = read_inference_data(input_files[0])
+    cov, _, dates = read_inference_data(input_files[0])
     with open(input_files[1], "rb") as f:
         samples = pkl.load(f)
     initial_state = samples.pop("initial_state")
     r_it = calc_posterior_rit(samples, initial_state, cov, device)
     N = np.asarray(cov.N, dtype=np.float64).reshape(-1)
     r_t = (r_it * (N / N.sum())[None, None, :]).sum(-1)
+    # the `posterior_predictive` group as the reference's xarray.Dataset.to_netcdf writes it
+    # (reproduction_number.py:73-88): R_it on (iteration, time, location), R_t on (iteration, time)
+    locations = read_location_names(input_files[0]) or [str(i) for i in range(r_it.shape[2])]
+    try:
+        times = np.array(dates, dtype="datetime64[D]") if "-" in str(dates[0]) else np.arange(r_it.shape[1])
+    except (ValueError, TypeError):
+        times = np.arange(r_it.shape[1])
     with hdf5io.File(output_file, "a") as f:
-        f.create_dataset("/posterior_predictive/R_it", r_it.shape, np.float64)
-        f.write("/posterior_predictive/R_it", r_it)
-        f.create_dataset("/posterior_predictive/R_t", r_t.shape, np.float64)
-        f.write("/posterior_predictive/R_t", r_t)
+        f.write_netcdf_group("posterior_predictive",
+                             {"iteration": np.arange(r_it.shape[0]), "time": times, "location": locations},
+                             {"R_it": (("iteration", "time", "location"), r_it), "R_t": (("iteration", "time"), r_t)})
     return r_it, r_t
 
 

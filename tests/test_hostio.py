@@ -1,4 +1,6 @@
 """CPU-only: HDF5 layer, inference-data round trip, Posterior layout, host init."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,6 +94,122 @@ def test_posterior_layout_matches_reference_schema(tmp_path):
         assert f.shape("/results/occult/E->I/is_accepted") == (n,)
         assert f.shape("/results/hmc/step_size") == (n,)
         assert f.shape("/initial_state") == (M, 4)
+
+
+H5PY_PYTHON = "/opt/conda/bin/python3.9"       # the only interpreter of this image with h5py (no xarray / netCDF4 anywhere)
+
+
+def _h5py(script, *args):
+    import subprocess
+    if not os.path.exists(H5PY_PYTHON):
+        pytest.skip("no h5py interpreter on this host")
+    r = subprocess.run([H5PY_PYTHON, "-c", script, *args], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_postprocessing_groups_have_the_layout_xarray_reads(tmp_path):
+    """predictions / posterior_predictive are written as `xarray.Dataset.to_netcdf(group=...)` lays a group out
+    (posterior/predict.py:124-147, reproduction_number.py:73-88): every dimension an HDF5 dimension scale holding
+    its coordinate -- integer ranges, LAD codes as variable-length strings, CF-encoded dates -- attached to every
+    axis of the variables, dimension ids unique in the file.  Checked with h5py, an independent reader."""
+    p = str(tmp_path / "out.nc")
+    rng = np.random.default_rng(3)
+    ev, init = rng.poisson(3.0, size=(4, 3, 5, 3)).astype(float), rng.uniform(0, 9, size=(4, 3, 4))
+    rit = rng.uniform(0.5, 2.0, size=(4, 6, 3))
+    days = np.datetime64("2021-02-27") + np.arange(5)
+    codes = ["E06000001", "N09000002", "S12000005"]
+    with hdf5io.File(p, "a") as f:
+        f.write_netcdf_group("predictions", {"iteration": np.arange(4), "location": codes, "time": days,
+                                             "event": np.arange(3), "state": np.arange(4)},
+                             {"events": (("iteration", "location", "time", "event"), ev),
+                              "initial_state": (("iteration", "location", "state"), init)})
+    with hdf5io.File(p, "a") as f:                      # a second group appended to the same file, as the pipeline does
+        f.write_netcdf_group("posterior_predictive", {"iteration": np.arange(4), "time": np.arange(6), "location": codes},
+                             {"R_it": (("iteration", "time", "location"), rit), "R_t": (("iteration", "time"), rit.mean(-1))})
+        with pytest.raises(ValueError):
+            f.write_netcdf_group("bad", {"a": np.arange(2)}, {"x": (("a",), np.zeros(3))})
+    np.save(tmp_path / "ev.npy", ev)
+    out = _h5py("""
+import sys, h5py, numpy as np
+f = h5py.File(sys.argv[1], "r")
+ev = np.load(sys.argv[2])
+g = f["predictions"]
+v = g["events"]
+assert v.shape == ev.shape and np.array_equal(v[...], ev)
+names = [v.dims[i][0].name.split("/")[-1] for i in range(4)]
+assert names == ["iteration", "location", "time", "event"], names
+assert [g["initial_state"].dims[i][0].name.split("/")[-1] for i in range(3)] == ["iteration", "location", "state"]
+for d in ("iteration", "location", "time", "event", "state"):
+    assert h5py.h5ds.is_scale(g[d].id) and g[d].attrs["CLASS"] == b"DIMENSION_SCALE" and "_Netcdf4Dimid" in g[d].attrs, d
+assert h5py.check_string_dtype(g["location"].dtype).length is None          # variable-length, as NC_STRING
+assert [x.decode() for x in g["location"][...]] == ["E06000001", "N09000002", "S12000005"]
+assert g["time"].attrs["units"] == b"days since 2021-02-27 00:00:00" and list(g["time"][...]) == [0, 1, 2, 3, 4]
+q = f["posterior_predictive"]
+assert [q["R_it"].dims[i][0].name.split("/")[-1] for i in range(3)] == ["iteration", "time", "location"]
+assert [q["R_t"].dims[i][0].name.split("/")[-1] for i in range(2)] == ["iteration", "time"]
+ids = [int(x.attrs["_Netcdf4Dimid"]) for grp in (g, q) for x in grp.values() if h5py.h5ds.is_scale(x.id)]
+assert len(set(ids)) == len(ids), ids
+assert np.isnan(v.attrs["_FillValue"][0])
+print("ok")
+""", p, str(tmp_path / "ev.npy"))
+    assert out.strip() == "ok"
+
+
+def test_is_accepted_is_the_bool_h5py_stores(tmp_path):
+    """gemlib's Posterior hands numpy bools to h5py, which stores them as the int8 enum {FALSE, TRUE}; downstream
+    (inference.py:594-605) reads them back as bools.  Ours must be the same type on disk."""
+    p = str(tmp_path / "posterior.hd5")
+    post = inf.Posterior(p, 3, 5, 2, 6)
+    acc = np.array([1, 0, 1, 1, 0, 1])
+    post.write("results/hmc/is_accepted", acc[:4], 0)
+    post.write("results/hmc/is_accepted", acc[4:].astype(bool), 4)
+    assert np.array_equal(post["results/hmc/is_accepted"], acc)
+    post.close()
+    with hdf5io.File(p, "r") as f:
+        assert np.array_equal(f.read("/results/hmc/is_accepted"), acc)
+        assert np.array_equal(f.read_rows("/results/hmc/is_accepted", 1, 2, 2), acc[1:5:2])
+    out = _h5py("""
+import sys, h5py, numpy as np
+d = h5py.File(sys.argv[1], "r")["results/hmc/is_accepted"]
+assert d.dtype == np.bool_, d.dtype
+assert d[...].tolist() == [True, False, True, True, False, True]
+assert h5py.File(sys.argv[1], "r")["results/move/S->E/is_accepted"].dtype == np.bool_
+print("ok")
+""", p)
+    assert out.strip() == "ok"
+
+
+def test_raw_datasets_are_written_and_read_one_way_only(tmp_path):
+    """A dataset whose rows go into the file at their address (raw=True) is never touched by H5Dwrite / H5Dread through
+    the same handle: write() on it takes the same path, read() and read_rows() fetch the bytes the same way -- before
+    the file is closed, with the library's buffers none the wiser -- and a dataset the library did not lay out as one
+    early-allocated contiguous extent is served by H5Dwrite."""
+    p = str(tmp_path / "raw2.h5")
+    rng = np.random.default_rng(8)
+    full = rng.integers(0, 999, size=(9, 4, 5, 3))
+    with hdf5io.File(p, "w") as f:
+        f.create_dataset("/samples/seir", full.shape, np.float64, raw=True)
+        assert "/samples/seir" in f._raw
+        f.write("/samples/seir", full[:4].astype(np.uint16), 0)                 # routed to the file-address path
+        f.write_rows_parallel("/samples/seir", full[4:], offset=4, threads=2)
+        assert np.array_equal(f.read("/samples/seir"), full)                    # same handle, no close in between
+        assert np.array_equal(f.read_rows("/samples/seir", 1, 3, 3), full[1:8:3])
+        f.create_dataset("/chunked", (8, 3), np.float64, chunk_rows=2, raw=False)
+        assert "/chunked" not in f._raw
+        f.create_dataset("/empty", (0, 3), np.float64, raw=True)                # nothing to address
+        assert "/empty" not in f._raw
+    with hdf5io.File(p, "r") as f:
+        assert np.array_equal(f.read("/samples/seir"), full)
+
+
+def test_event_trace_width_is_chosen_from_the_data():
+    assert inf.trace_events_dtype(np.full((3, 4), 120.0)) == "u16"
+    assert inf.trace_events_dtype(np.array([[10.0, 5000.0]])) is True           # 16 x 5000 > 65535: int32
+    assert inf.trace_events_dtype(np.zeros((0, 4))) == "u16"
+    assert inf.trace_events_dtype(np.full((2, 2), 9e4), "u16") == "u16" and inf.trace_events_dtype(np.ones((2, 2)), "int32") is True
+    with pytest.raises(ValueError):
+        inf.trace_events_dtype(np.ones((2, 2)), "u8")
 
 
 def test_initial_conditions_follow_reference_recipe():

@@ -593,20 +593,23 @@ def test_compact_event_trace_is_lossless_and_guards_its_range(api):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 3, 8, 12, 16])
 def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
-    """hmc="chunk" (any number of chains, in the layout of the next multiple of 8: chain b on XCD b mod 8) runs the chunk roles of a leapfrog step inside the gradient launch (k_se_chunk: the
-    last workgroups of a chain to arrive take the roles; hand-off through the XCD's L2) when the GPU places block ids
-    congruent mod 8 on one XCD each; hmc="chunk-split" launches them separately.  Same arithmetic in the same order:
-    every traced quantity must agree to the last bit, with and without workgroup skew."""
+    """hmc="chunk" (any number of chains, in the layout of the next multiple of 8: chain b on XCD b mod 8) runs ALL inner
+    leapfrog steps in one persistent launch (k_leap: the gradient tiles keep their cells in registers over the steps;
+    tiles and chunk roles hand each other partial sums and tables through the XCD's L2) where every workgroup of that
+    launch fits the chip, hmc="chunk-launch" one launch per step with the chunk roles inside the gradient launch
+    (k_se_chunk) -- both only when the GPU places block ids congruent mod 8 on one XCD each -- and hmc="chunk-split"
+    launches tiles and roles separately.  Same arithmetic in the same order: every traced quantity must agree to the last
+    bit, with and without workgroup skew."""
     case = H.build_case("ni11", 31)
     u = synth.jitter_params(case["u"], B, scale=0.01, seed=3, T=case["k"].T)
     ev = np.stack([case["events"]] * B)
     cfg = dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=2)
     out = {}
-    for mode, skew in (("chunk-split", 0), ("chunk", 0), ("chunk", 2)):
+    for mode, skew in (("chunk-split", 0), ("chunk", 0), ("chunk", 2), ("chunk-launch", 0), ("chunk-launch", 1)):
         with api[0](case["cov"], case["init"], max_chains=B) as model:
             model.set_option(debug_skew=skew)
             with api[1](model, cfg, B, seed=77, trace_capacity=40, hmc=mode) as s:
-                if mode == "chunk" and not s.xcd_local():
+                if mode != "chunk-split" and not s.xcd_local():
                     pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the fused form is not used")
                 s.set_state(u, ev)
                 s.set_kernel(step_size=0.02)
@@ -616,12 +619,43 @@ def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
                 assert not s.pair_timeouts().any()
                 out[(mode, skew)] = tr
     ref = out[("chunk-split", 0)]
-    for key in (("chunk", 0), ("chunk", 2)):
+    for key in (("chunk", 0), ("chunk", 2), ("chunk-launch", 0), ("chunk-launch", 1)):
         got = out[key]
         assert np.array_equal(ref.theta, got.theta), key
         assert np.array_equal(ref.events, got.events), key
         for k in ref.hmc:
             assert np.array_equal(ref.hmc[k], got.hmc[k]), (key, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,eps", [("uk380", 8, 1.2e-5), ("uk380", 3, 1.2e-5), ("slow_520x60", 2, 3e-5), ("micro_17x70", 8, 0.0004)])
+def test_leapfrog_launch_forms_give_the_same_bits_at_size(api, name, B, eps):
+    """The same comparison where the persistent launch has something to get wrong: the headline size (72 tile workgroups
+    and 12 four-wave roles per chain, six day chunks, eight counter shards), a partial layout of 8, and M > 512 (the tiles
+    also form the row scalars: the second instance of the kernels).  Three sweeps with all updates on."""
+    case = H.build_case(name, 43, alpha_t_sd=0.005)
+    u = synth.jitter_params(case["u"], B, scale=0.002 if name == "uk380" else 0.01, seed=3, T=case["k"].T)
+    ev = np.stack([case["events"]] * B)
+    cfg = CFG_REF if name == "uk380" else CFG_SMALL
+    out = {}
+    for mode, skew in (("chunk-split", 0), ("chunk-launch", 0), ("chunk", 0), ("chunk", 3)):
+        with api[0](case["cov"], case["init"], max_chains=B) as model:
+            model.set_option(debug_skew=skew)
+            with api[1](model, cfg, B, seed=13, trace_capacity=3, hmc=mode) as s:
+                if mode != "chunk-split" and not s.xcd_local():
+                    pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the fused forms are not used")
+                s.set_state(u, ev)
+                s.set_kernel(step_size=eps)
+                out[(mode, skew)] = (s.sample(3), s.get_state())
+                assert not s.pair_timeouts().any()
+    ref, ref_state = out[("chunk-split", 0)]
+    assert ref.hmc["is_accepted"].any()
+    for key, (got, got_state) in out.items():
+        assert np.array_equal(ref.theta, got.theta), key
+        assert np.array_equal(ref.events, got.events), key
+        for k in ref.hmc:
+            assert np.array_equal(ref.hmc[k], got.hmc[k]), (key, k)
+        assert np.array_equal(ref_state[0], got_state[0]) and np.array_equal(ref_state[2], got_state[2]), key
 
 
 @pytest.mark.gpu

@@ -208,7 +208,10 @@ def test_predict_end_to_end(tmp_path):
     assert np.array_equal(init[0], state[:, k.T - 7, :])
     with hdf5io.File(out, "r") as f:
         assert np.array_equal(f.read("/predictions/events"), ev)
-        assert f.read("/predictions/time")[0].decode() == dates[k.T - 7]
+        # the time coordinate, CF-encoded as xarray writes it (days since the first predicted day)
+        assert f.read_str_attr("/predictions/time", "units") == f"days since {dates[k.T - 7]} 00:00:00"
+        assert np.array_equal(f.read("/predictions/time"), np.arange(21))
+        assert f.shape("/predictions/initial_state") == (n, k.M, 4)
     # in-sample prediction reproduces through the oracle
     samples2 = {kk: v for kk, v in samples.items() if kk != "initial_state"}
     init2, ev2 = pp.predicted_incidence(samples2, case["init"], cov, 3, 10, out_of_sample=False, seed=8)
