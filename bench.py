@@ -270,11 +270,16 @@ def main():
         sampler.sample_bursts(n_bursts, burst, lambda tr_, i: touched.append(int(tr_.events[-1, 0, 0, 0, 0])))
         overlapped = time.perf_counter() - t2
 
-    # dominant kernel of the sweep: the gradient kernel (17 launches per sweep)
+    # dominant kernel of the sweep: the gradient evaluation, 17 per sweep.  15 of them are the inner leapfrog steps -- ONE
+    # persistent launch (k_leap) where it fits the chip, else one k_se_chunk launch per step -- timed in place: HIP events
+    # around that section of ordinary sweeps, on the stream the kernels run on.  The other two are plain k_se launches
+    # (first and last gradient of a trajectory), timed stand-alone.
+    leap_ms, leap_launches, leap_evals = sampler.time_leapfrog(min(200, max(20, K)))
     grad_ms = sampler.time_grad_kernel(200)
     M, T, P = cov.M, cov.T, model.P
     alg_bytes = B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
-    achieved = alg_bytes / (grad_ms * 1e-3) / 1e9
+    achieved = leap_evals * alg_bytes / (leap_ms * 1e-3) / 1e9
+    achieved_k_se = alg_bytes / (grad_ms * 1e-3) / 1e9
     # what this kernel itself moves: int32 k_se, S, I + fp64 F per padded cell (20 B), the per-row /
     # per-day tables, and its partial sums out (row sums per day chunk, column sums per row tile, 4 tile scalars)
     Mp, Tp = -(-M // 64) * 64, -(-T // 64) * 64
@@ -282,12 +287,15 @@ def main():
     kernel_bytes = B * (20 * Mp * Tp + 8 * (Mp + 2 * Tp) + 8 * (ntc * Mp + nmt * Tp) + 8 * 6 * nmt * ntc)
     # HBM-side traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this
     # process): FETCH_SIZE x the gfx950 calibration factor + WRITE_SIZE, same workload and batch.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_k_se = None, None, None
     import glob
     pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if a.workload == "uk380" and B == 8 and pmcs:
         doc = json.load(open(pmcs[-1]))
         ent = doc.get("k_se<GRAD=true,SRC=planes>")
+        if ent:
+            traffic_k_se = ent["traffic_bytes_per_launch"]
+        ent = doc.get("k_leap" if leap_launches == 1 else "k_se_chunk")
         if ent:
             traffic = ent["traffic_bytes_per_launch"]
             traffic_src = "profiles/" + os.path.basename(pmcs[-1])
@@ -413,10 +421,13 @@ def main():
             sx.run(40)
             msx = mx.timer_stop()
             gx = sx.time_grad_kernel(100)
+            lmx, llx, lex = sx.time_leapfrog(20)
             bytes_x = Bx * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
             scaling[str(Bx)] = {"samples_per_sec": Bx * 40 / (msx * 1e-3), "ms_per_step": msx / 40,
                                 "grad_kernel_us": 1e3 * gx,
-                                "grad_kernel_frac_of_hbm_peak": bytes_x / (gx * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                                "grad_kernel_frac_of_hbm_peak": bytes_x / (gx * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "leapfrog_section_us": 1e3 * lmx, "leapfrog_launches": llx,
+                                "leapfrog_frac_of_hbm_peak": lex * bytes_x / (lmx * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             sx.close()
             mx.close()
 
@@ -467,16 +478,32 @@ def main():
                        "sweep": "HMC(16 leapfrogs) + 5 x [S->E move, E->I move, S->E occult, E->I occult]",
                        "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] (uint16 counts) + kernel results per sweep",
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"kernel": "k_se<GRAD=true,SRC=planes> (S->E term + gradient sums, all chains; 17 gradient evaluations per sweep: "
-                                   "2 as this kernel, 15 as the tile phase of k_se_chunk, which then runs the leapfrog update in the same launch)",
+            "roofline": {"kernel": ("k_leap<TSM,NTC,2> (persistent: the 15 inner leapfrog steps of a trajectory in one launch -- per step the "
+                                    "S->E term + gradient sums of all chains from register-resident cells, then the chunk roles' leapfrog "
+                                    "update; 15 of the sweep's 17 gradient evaluations)") if leap_launches == 1 else
+                                   ("k_se_chunk (one launch per inner leapfrog step: gradient tiles + chunk roles; 15 of the sweep's 17 "
+                                    "gradient evaluations)" if leap_launches == leap_evals else
+                                    "k_se + k_hmc_chunk (two launches per inner leapfrog step; 15 of the sweep's 17 gradient evaluations)"),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_uses": "algorithmic_bytes_per_launch (SURVEY.md 8d: fp64 events + Cstar once per launch)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": 1e3 * grad_ms,
-                         "kernel_bytes_per_launch": kernel_bytes,
-                         "frac_kernel_bytes": kernel_bytes / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "frac_traffic": (traffic / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "launches_per_sweep": 17},
+                         "frac_uses": "algorithmic bytes of SURVEY.md 8d (fp64 events + vectors per chain, Cstar once) x the gradient "
+                                      "evaluations the timed section performs / its duration (HIP events around it in ordinary sweeps)",
+                         "algorithmic_bytes_per_evaluation": alg_bytes, "evaluations_per_section": leap_evals,
+                         "launches_per_section": leap_launches, "section_us": 1e3 * leap_ms,
+                         "us_per_evaluation": 1e3 * leap_ms / leap_evals,
+                         "mean_launch_us": 1e3 * leap_ms / leap_launches,
+                         "note": "the persistent kernel reads its cells from HBM once per trajectory and keeps them in registers, so its "
+                                 "memory traffic is far below the algorithmic bytes: what bounds it is the fp64 vector issue rate of the "
+                                 "tile phase (~70 instructions per cell) and the two in-L2 hand-offs per step -- `frac` prices it "
+                                 "against the HBM time of the algorithmic bytes as SURVEY.md 8d defines",
+                         "k_se_stand_alone": {"kernel": "k_se<GRAD=true,SRC=planes> (the other 2 of the 17 evaluations)",
+                                              "mean_launch_us": 1e3 * grad_ms, "achieved": achieved_k_se,
+                                              "frac": achieved_k_se / HBM_PEAK_GBPS,
+                                              "kernel_bytes_per_launch": kernel_bytes,
+                                              "frac_kernel_bytes": kernel_bytes / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                              "frac_traffic": (traffic_k_se / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_k_se else None,
+                                              "traffic": traffic_k_se},
+                         "frac_time_weighted_17": (17 * alg_bytes / ((leap_ms + 2 * grad_ms) * 1e-3) / 1e9) / HBM_PEAK_GBPS},
             "roofline_stateless": stateless,
             "spinup_sweeps": spin_sweeps,
             "steady_state": steady,

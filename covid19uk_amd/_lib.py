@@ -125,6 +125,8 @@ _SIGNATURES = {
                                                ctypes.c_void_p, c_double_p, c_double_p]),
     "seir_sampler_time_grad_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.POINTER(ctypes.c_float)]),
+    "seir_sampler_time_leapfrog": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_float),
+                                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "seir_sampler_pair_timeouts": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
     "seir_sampler_xcd_local": (ctypes.c_int, [ctypes.c_void_p]),
 }

@@ -1412,7 +1412,7 @@ template <int TSM, int NST>
 __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s, const Chains &ch,
                                           int bx, int byg, int bz, int par0, int nsteps, unsigned long long step_base) {
     __shared__ double colbuf[NST][4][WAVE];
-    __shared__ double llbuf[NST][4][WAVE], psibuf[NST][4][WAVE];
+    __shared__ double psibuf[NST][4][WAVE];
     __shared__ double rowbuf[NST][4 * SE_RW * SE_RS];
     __shared__ double rlbuf[TSM == 2 ? NST : 1][4][WAVE], rsbuf[TSM == 2 ? NST : 1][4][WAVE];
     __shared__ double2 ltab[LDSTAB_N];
@@ -1500,8 +1500,10 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
                 ts_s[r] = ts_rows ? tabbuf[TB_SP + st * SE_TM + wave * SE_RW + r] : 0.0;
             }
             double *myrow = rowbuf[st] + wave * SE_RW * SE_RS;
-            double ll = 0.0, gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0;
-            // the four cells side by side (se_cells: se_tile's own evaluation)
+            double gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0;
+            // the four cells side by side (se_cells: se_tile's own evaluation).  Only the GRADIENT of the S->E term drives a
+            // leapfrog step: the term's value (and with it log(1 - e^-r), a third of a cell's instructions) is needed at the
+            // trajectory's end points alone, which k_se evaluates -- L is left unused here and the compiler drops its chain
             double Id[SE_RW], ee[SE_RW], lam0[SE_RW], rr[SE_RW], L[SE_RW], inv[SE_RW];
 #pragma unroll
             for (int r = 0; r < SE_RW; ++r) Id[r] = (double)Ii[st][r];
@@ -1510,7 +1512,6 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             for (int r = 0; r < SE_RW; ++r) {
                 const double kse = (double)ki[st][r], snk = (double)(si[st][r] - ki[st][r]);
                 const bool has = kse != 0.0;
-                ll += (has ? kse * L[r] : 0.0) - snk * rr[r];
                 const double gl = d.dt * ((has ? kse * inv[r] : 0.0) - snk);
                 const double ge = gl * lam0[r];
                 myrow[r * SE_RS + lane] = ge;
@@ -1521,7 +1522,6 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
                 }
                 gpsi += gl * ee[r] * Wt * F[st][r];
             }
-            llbuf[st][wave][lane] = ll;
             psibuf[st][wave][lane] = gpsi;
             colbuf[st][wave][lane] = colacc;
             {
@@ -1546,8 +1546,7 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             const int by = byg * NST + st;
             const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
             if (wave == 0) {
-                const double v = wave_sum((llbuf[st][0][lane] + llbuf[st][1][lane]) + (llbuf[st][2][lane] + llbuf[st][3][lane]));
-                if (lane == 0) w.Lpart[tile] = v;
+                // (no log-likelihood partial: see above)
             } else if (wave == 1) {
                 const double v = wave_sum((psibuf[st][0][lane] + psibuf[st][1][lane]) + (psibuf[st][2][lane] + psibuf[st][3][lane]));
                 if (lane == 0) w.Ppart[tile] = v;

@@ -961,6 +961,9 @@ struct seir_sampler {
     bool hmc_tail = true;         // hmc_mode 0 / 3: chunk roles inside the gradient launch (k_se_chunk) where xcd_local holds
     bool hmc_leap = true;         // hmc_mode 0: all inner steps in one persistent launch (k_leap) where every workgroup fits the chip
     int leap_occ[2][3][2];        // workgroups of k_leap<TSM, NTC, NST> the chip holds at once (occupancy query, cached; -1: not asked yet)
+    // seir_sampler_time_leapfrog: HIP events around the inner leapfrog steps of each sweep while it is on
+    std::vector<hipEvent_t> prof_ev;     // pairs (before, after)
+    int prof_i = -1, prof_launches = 0;  // next pair to record (-1: off); launches of the section in the last sweep
     unsigned long long leap_steps = 0;   // leapfrog steps done by all k_leap launches so far (what Chains::leap's flags show)
     bool xcd_local = false;       // blocks with the same id mod 8 share an XCD (k_xcc_probe at creation)
     unsigned long long tail_count = 0;   // tiles per chain counted in by all k_se_chunk launches so far (Chains::tail)
@@ -990,6 +993,8 @@ static void drop_graph(seir_sampler *s) {
 }
 
 extern "C" void seir_sampler_destroy(seir_sampler *s) {
+    if (s) for (hipEvent_t e : s->prof_ev) (void)hipEventDestroy(e);
+    if (s) s->prof_ev.clear();
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
@@ -1407,6 +1412,8 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                           !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && ts_mode != 0;
         // all of them in ONE persistent launch (k_leap: the tiles keep their cells in registers over the steps) when every
         // workgroup of that launch can be resident at once -- its tiles wait for the roles
+        const bool prof = s->prof_i >= 0 && (size_t)(2 * s->prof_i + 1) < s->prof_ev.size() && g == 0;
+        if (prof) (void)hipEventRecord(s->prof_ev[2 * s->prof_i], st);
         bool leap = false;
         int leap_nst = 1;
         if (tail && s->hmc_leap && c.L >= 3 && d0.nmt <= WAVE) {     // (role_gather: a lane per row tile)
@@ -1472,6 +1479,11 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             par ^= 1;
         }
         l.d.sp_par = par;
+        if (prof) {
+            (void)hipEventRecord(s->prof_ev[2 * s->prof_i + 1], st);
+            s->prof_i += 1;
+            s->prof_launches = leap ? 1 : tail ? c.L - 1 : 2 * (c.L - 1);
+        }
     }
     l.d.chunked = 0;
     launch_se<1>(ctx, l, true);
@@ -1729,6 +1741,37 @@ extern "C" int seir_sampler_time_grad_kernel(seir_sampler *s, int32_t iters, flo
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     HIP_TRY(hipGetLastError());
     *mean_ms = ms / iters;
+    return 0;
+}
+
+extern "C" int seir_sampler_time_leapfrog(seir_sampler *s, int32_t sweeps, float *mean_ms, int32_t *launches, int32_t *evals) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
+    if (!mean_ms || sweeps < 1 || sweeps > 4096) return fail(SEIR_ERR_INVALID, "bad sweeps/mean_ms");
+    if (s->use_graph || s->ngroups != 1) return fail(SEIR_ERR_STATE, "timing of the leapfrog section needs stream launches on one stream");
+    while (s->prof_ev.size() < (size_t)2 * sweeps) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->prof_ev.push_back(e);
+    }
+    s->prof_i = 0;
+    s->prof_launches = 0;
+    rc = seir_sampler_run(s, sweeps);
+    const int recorded = s->prof_i;
+    s->prof_i = -1;
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    if (recorded < 1) return fail(SEIR_ERR_STATE, "this sampler's sweep has no chunked leapfrog section (hmc_mode 1 or fewer than 3 leapfrog steps)");
+    double sum = 0.0;
+    for (int i = 0; i < recorded; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->prof_ev[2 * i], s->prof_ev[2 * i + 1]));
+        sum += ms;
+    }
+    *mean_ms = (float)(sum / recorded);
+    if (launches) *launches = s->prof_launches;
+    if (evals) *evals = s->cfg.L - 1;
     return 0;
 }
 

@@ -293,6 +293,13 @@ class ChainSampler:
         _lib.check(self._lib.seir_sampler_pair_timeouts(self._s, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
         return out
 
+    def time_leapfrog(self, sweeps: int = 50):
+        """(mean ms, launches, gradient evaluations) of the inner leapfrog steps of a sweep -- HIP events around that
+        section of `sweeps` ordinary sweeps, on the stream the kernels run on (seir_sampler_time_leapfrog)."""
+        ms_, nl, ne = ctypes.c_float(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._lib.seir_sampler_time_leapfrog(self._s, int(sweeps), ctypes.byref(ms_), ctypes.byref(nl), ctypes.byref(ne)))
+        return float(ms_.value), int(nl.value), int(ne.value)
+
     def time_grad_kernel(self, iters: int = 100) -> float:
         """Mean duration (ms) of the sweep's gradient kernel, HIP events on the context stream."""
         ms_ = ctypes.c_float()

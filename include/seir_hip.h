@@ -294,6 +294,13 @@ int seir_sampler_xcd_local(seir_sampler *s);
  * 0 outside the debug_pair test hooks. */
 int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out);
 
+/* Measurement hook (no reference counterpart): runs `sweeps` ordinary sweeps with a pair of HIP events around the
+ * inner leapfrog steps 1..L-1 of each -- the section in which 15 of the sweep's 17 gradient evaluations happen -- on
+ * the stream the kernels are launched on.  mean_ms = mean duration of that section; launches = kernel launches in it
+ * (1: the persistent k_leap, L-1: k_se_chunk per step, 2(L-1): k_se + k_hmc_chunk); evals = gradient evaluations in
+ * it (L-1).  The chains advance as in seir_sampler_run. */
+int seir_sampler_time_leapfrog(seir_sampler *s, int32_t sweeps, float *mean_ms, int32_t *launches, int32_t *evals);
+
 /* ------------------------------------------------------------------------
  * Reproduction number R_it.
  *

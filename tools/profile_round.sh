@@ -26,4 +26,16 @@ rocprofv3 -L > "$out/counters.txt" 2>&1 || true
 if [ -x tools/probes/se_probe ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_probe" -o k -- tools/probes/se_probe > "$out/pmc_probe.log" 2>&1
 fi
+# 4. BASELINE config 5 (SYN-2048 x 730, 8 chains): the bench line, kernel stats of a short sampler run, and the matrix-core
+#    counters of the fp32 and fp64 contraction kernels (SQ counters only, in passes of their own)
+python3 bench.py --workload syn2048 --steps 20 --warmup 3 --adapt-sweeps 10 > "$out/bench_syn2048.json" 2> "$out/bench_syn2048.err" \
+  || echo "syn2048 bench failed (see $out/bench_syn2048.err)"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_syn2048" -o k -- python3 tools/quick_sweep_bench.py --workload syn2048 --groups 1 --sweeps 10 \
+    > "$out/stats_syn2048.log" 2>&1 || echo "syn2048 kernel stats failed"
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES \
+    --output-format csv -d "$out/pmc_mfma_syn_f32" -o k -- python3 tools/quick_eval_bench.py --workload syn2048 --iters 3 --form four-launch --gemm-f32 1 \
+    > "$out/pmc_mfma_syn_f32.log" 2>&1 || echo "syn2048 fp32 MFMA counter pass failed"
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES \
+    --output-format csv -d "$out/pmc_mfma_syn_f64" -o k -- python3 tools/quick_eval_bench.py --workload syn2048 --iters 3 --form four-launch \
+    > "$out/pmc_mfma_syn_f64.log" 2>&1 || echo "syn2048 fp64 MFMA counter pass failed"
 echo "raw output in $out; now run: python3 tools/summarize_profiles.py $tag $out  (here or after gpurun merged gpurun_out/ back)"

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--chains", type=int, default=8)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--form", default="fused", choices=["fused", "three-launch", "four-launch"])
+    ap.add_argument("--gemm-f32", type=int, default=0, help="1: the fp32 MFMA mobility contraction (BASELINE config 5)")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as entry
@@ -37,7 +38,10 @@ def main():
     out = {"workload": args.workload, "B": B, "M": cov.M, "T": cov.T}
     with SeirModel(cov, init, max_chains=B) as model:
         model.set_option(eval_form=args.form)
+        if args.gemm_f32:
+            model.set_option(gemm_f32=True)
         out["form"] = args.form
+        out["gemm_f32"] = bool(args.gemm_f32)
         for grad in (None, g):
             for _ in range(3):
                 model.log_prob_dev(ut, evt, lp, grad)

@@ -20,10 +20,11 @@ import shutil
 import sys
 from collections import defaultdict
 
-# the sampler's gradient kernel: any instance of k_se<GRAD=true, SRC=1, TSM> (the template tail has
-# changed between rounds; the instance with the most launches is the dominant one)
-DOMINANT_PREFIX = "void seir::k_se<true, 1"
-DOMINANT_KEY = "k_se<GRAD=true,SRC=planes>"
+# the sampler's gradient kernels: the persistent leapfrog launch (k_leap, 15 evaluations per launch), its per-step form
+# (k_se_chunk) and the plain gradient kernel k_se<GRAD=true, SRC=1, TSM> (2 of the 17 evaluations of a sweep); of each
+# family the instance with the most launches
+FAMILIES = {"k_leap": "void seir::k_leap<", "k_se_chunk": "void seir::k_se_chunk<",
+            "k_se<GRAD=true,SRC=planes>": "void seir::k_se<true, 1"}
 PROBE = "void k_var<1, 8>"
 PROBE_BYTES = 8 * 384 * 384 * 20
 
@@ -72,11 +73,12 @@ def main():
             continue
         means = counter_means(p)
         write_means(os.path.join(prof, f"{tag}_pmc_{c}.csv"), means)
-        cands = [(n, k) for (k, cc), (m, n) in means.items() if cc == c and k.startswith(DOMINANT_PREFIX)]
-        if cands:
-            dominant = max(cands)[1]
-            vals[c] = means[(dominant, c)][0]
-            names[c] = dominant
+        for fam, prefix in FAMILIES.items():
+            cands = [(n, k) for (k, cc), (m, n) in means.items() if cc == c and k.startswith(prefix)]
+            if cands:
+                dominant = max(cands)[1]
+                vals[(fam, c)] = means[(dominant, c)][0]
+                names[fam] = dominant
     factor = None
     p = one(os.path.join(raw, "pmc_probe", "**", "*counter_collection.csv"))
     if p:
@@ -89,13 +91,14 @@ def main():
                                       "known_bytes": PROBE_BYTES, "FETCH_SIZE_KB": kb, "factor": factor,
                                       "note": "gfx950 FETCH_SIZE counts 64 B per 128-B request: factor ~2 "
                                               "(MI355X_MICROARCH.md, HBM)"}
-    if "FETCH_SIZE" in vals:
-        f = factor if factor else 2.0
-        traffic = vals["FETCH_SIZE"] * 1024.0 * f + vals.get("WRITE_SIZE", 0.0) * 1024.0
-        summary[DOMINANT_KEY] = {
-            "kernel_name": names["FETCH_SIZE"].replace("void seir::", ""),
-            "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals.get("WRITE_SIZE"),
-            "fetch_factor": f, "traffic_bytes_per_launch": traffic}
+    for fam in FAMILIES:
+        if (fam, "FETCH_SIZE") in vals:
+            f = factor if factor else 2.0
+            traffic = vals[(fam, "FETCH_SIZE")] * 1024.0 * f + vals.get((fam, "WRITE_SIZE"), 0.0) * 1024.0
+            summary[fam] = {
+                "kernel_name": names[fam].replace("void seir::", ""),
+                "FETCH_SIZE_KB": vals[(fam, "FETCH_SIZE")], "WRITE_SIZE_KB": vals.get((fam, "WRITE_SIZE")),
+                "fetch_factor": f, "traffic_bytes_per_launch": traffic}
     # matrix-core counters of the stateless evaluation (k_eval_tiles; k_gemm in the four-launch form): one SQ pass
     p = one(os.path.join(raw, "pmc_mfma", "**", "*counter_collection.csv"))
     if p:
@@ -109,6 +112,28 @@ def main():
             summary["mfma_counters"] = {
                 "source": "rocprofv3 --pmc (SQ counters, own pass) over tools/quick_eval_bench.py (UK-380 x 365, 8 chains)",
                 "per_launch_mean": mf}
+    # BASELINE config 5 (SYN-2048 x 730): bench line, kernel stats, matrix-core counters of the contraction kernels
+    src = os.path.join(raw, "bench_syn2048.json")
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copy(src, os.path.join(prof, f"{tag}_syn2048_bench.json"))
+    stats = one(os.path.join(raw, "stats_syn2048", "**", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats, os.path.join(prof, f"{tag}_syn2048_kernel_stats.csv"))
+    syn = {}
+    for kind in ("f32", "f64"):
+        p = one(os.path.join(raw, f"pmc_mfma_syn_{kind}", "**", "*counter_collection.csv"))
+        if not p:
+            continue
+        means = counter_means(p)
+        write_means(os.path.join(prof, f"{tag}_syn2048_pmc_mfma_{kind}.csv"), means)
+        for (k, c), (m, n) in means.items():
+            if "k_gemm" in k:
+                syn.setdefault(kind, {}).setdefault(k.replace("void seir::", ""), {})[c] = m
+    if syn:
+        summary["mfma_counters_syn2048"] = {
+            "source": "rocprofv3 --pmc (SQ counters, own passes) over tools/quick_eval_bench.py --workload syn2048 "
+                      "--form four-launch [--gemm-f32 1] (SYN-2048 x 730, 8 chains)",
+            "per_launch_mean": syn}
     with open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w") as fo:
         json.dump(summary, fo, indent=1)
     print(json.dumps(summary, indent=1))
