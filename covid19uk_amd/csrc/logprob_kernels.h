@@ -90,6 +90,8 @@ struct Work {
     double *scal;          // [B][NSCAL]
     double *Qs;            // [B][Mp]   car_Q . spatial_effect
     double *Lpart, *Ppart; // [B][nmt*ntc]
+    double *Lpart0;        // [B][nmt*ntc] sampler, k_leap: the S->E term's partial sums at the START point of a trajectory (Lpart
+                           //              is overwritten by the end point's)
     double *Kpart;         // [B][nmt][Tp]
     double *Rpart;         // [B][ntc][Mp]
     // chunked leapfrog (sampler only; null on a plain context) -- see k_hmc_chunk in sampler_kernels.h
@@ -646,7 +648,9 @@ inline bool xcd_affinity_applies(int per, int nb) {
 // issue) -- and a cell whose rate is outside the series' range (rare: daily hazards are 1e-5..1e-2) is redone by the full
 // l1me_inv in a cold block.  One definition for every kernel that evaluates the term (k_se, k_se_chunk, k_leap): the
 // sampler's launch forms must give the same bits.
-template <int NR>
+// WANT_L = false (the inner leapfrog steps of k_leap: only the gradient of the term is needed): L is left at 0 and its
+// chain -- the table logarithm, a third of a cell's instructions -- is not evaluated.
+template <int NR, bool WANT_L = true>
 __device__ __forceinline__ void se_cells(double ea_t, const double (&eb)[NR], const double (&I)[NR], double psiW, const double (&F)[NR],
                                          double rate_floor, double dt, const double2 *ltab, const SeK &sk,
                                          double (&ee)[NR], double (&lam0)[NR], double (&rr)[NR], double (&L)[NR], double (&inv)[NR]) {
@@ -657,12 +661,30 @@ __device__ __forceinline__ void se_cells(double ea_t, const double (&eb)[NR], co
         lam0[r] = ee[r] * (I[r] + psiW * F[r]);
         rr[r] = (lam0[r] + rate_floor) * dt;
         l1me_inv_series_k(rr[r], L[r], inv[r], ltab, sk);
+        if (!WANT_L) L[r] = 0.0;
         odd = odd || !(rr[r] >= L1ME_SERIES_MIN && rr[r] <= L1ME_SERIES_MAX);
     }
     if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             if (!(rr[r] >= L1ME_SERIES_MIN && rr[r] <= L1ME_SERIES_MAX)) l1me_inv(rr[r], L[r], inv[r], ltab);
+    }
+}
+
+// L = log(1 - e^-r) of cells whose rates se_cells<NR, false> has formed: the end points of a trajectory inside k_leap
+// (a cold block there; the same series and the same fallback as se_cells)
+template <int NR>
+__device__ __forceinline__ void se_cells_L(const double (&rr)[NR], const double2 *ltab, const SeK &sk, double (&L)[NR]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double x = rr[r];
+        if (x >= L1ME_SERIES_MIN && x <= L1ME_SERIES_MAX) {
+            const double x2 = x * x;
+            L[r] = fast_log_k(x, ltab, sk) + x * (sk.mhalf + x * (sk.l1 - x2 * (sk.l2 - x2 * (sk.l3 - x2 * sk.l4))));
+        } else {
+            double inv_;
+            l1me_inv(x, L[r], inv_, ltab);
+        }
     }
 }
 

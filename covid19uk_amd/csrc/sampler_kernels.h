@@ -99,6 +99,9 @@ struct Chains {
                                                          //     then [B][TAIL_FLAG_STRIDE]: the count at which the chain's last tile raised
                                                          //     the flag the roles poll
     unsigned long long *leap;                            // [B][LEAP_CH] k_leap's counters and flags (see there), a chain's in its own 8 KB
+    double *k0part;                                      // [B][32] k_leap with the trajectory's first step folded in: the roles' parts of
+                                                         //         the start point's kinetic energy
+    double *irl0;                                        // [B] ... and the I->R term of its log-probability
     unsigned long long *leap_st;                         // [B][16][8] developer timeline of k_leap (LEAP_STAMPS builds only)
     unsigned *hand2;                                     // [B] the same token for role 2 (pre-drawn S->E-type proposal)
     Move *mvs;                                           // [2][B] S->E-type proposal pre-drawn for the next launch (k_move_pair, role 2)
@@ -600,18 +603,19 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
     STAMP(5);
     // write back position / momentum
 #pragma unroll
+    // (stage 2 leaves q0 = q: the start point of the next trajectory, which a folded first step reads from q0)
     for (int k = 0; k < HT; ++k) {
         const int t = tid + k * HB;
-        if (t >= 1 && t < T) { q[oT + t] = qa[k]; if (STAGE != 2) p[oT + t] = pa[k]; }
+        if (t >= 1 && t < T) { q[oT + t] = qa[k]; if (STAGE != 2) p[oT + t] = pa[k]; else q0[oT + t] = qa[k]; }
     }
 #pragma unroll
     for (int k = 0; k < HM; ++k) {
         const int m = tid + k * HB;
-        if (m < M) { q[oM + m] = qm[k]; if (STAGE != 2) p[oM + m] = pm[k]; lds_sp[m] = qm[k]; }
+        if (m < M) { q[oM + m] = qm[k]; if (STAGE != 2) p[oM + m] = pm[k]; else q0[oM + m] = qm[k]; lds_sp[m] = qm[k]; }
     }
     if (tid == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { q[i] = q6[i]; if (STAGE != 2) p[i] = p6[i]; }
+        for (int i = 0; i < 6; ++i) { q[i] = q6[i]; if (STAGE != 2) p[i] = p6[i]; else q0[i] = q6[i]; }
         bc[2] = q6[2]; bc[3] = q6[3]; bc[4] = q6[4]; bc[5] = q6[5];
         bc[6] = q6[0]; bc[7] = q6[1];
     }
@@ -801,13 +805,31 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
 //   T-chunk: wave w accumulates the column sums of row tiles w, w+4, w+8 ... (k_hmc_chunk's accumulator c_w) and fetches the
 //            tile scalars of day chunks w, w+4, w+8.
 //   M-chunk: wave 1 the row partials of the chunk's own rows, wave 2 the per-tile psi partials (and row scalars), and for the
-//            small-M form (the M-chunks sum the row partials of ALL rows themselves) rows kk of a lane by waves 0,0,1,2,3,3,1,2.
+//            small-M form (the M-chunks sum the row partials of ALL rows themselves) rows kk of a lane by waves 1,2,3,1,2,3,1,2.
 template <int NC> struct RoleGather {                           // offsets (doubles) into the role's LDS block
     static constexpr int C = 0, BS = 4 * WAVE, AS = BS + NC * WAVE;                              // T-chunk
-    static constexpr int X = 0, PS = NC * WAVE, RL = PS + WAVE, RS = RL + WAVE, ACC = RS + WAVE;   // M-chunk
-    static constexpr int SIZE = (4 + 2 * NC) * WAVE > (NC + 3 + 8) * WAVE ? (4 + 2 * NC) * WAVE : (NC + 3 + 8) * WAVE;
+    static constexpr int X = 0, PS = NC * WAVE, RL = PS + WAVE, RS = RL + WAVE, ACC = RS + WAVE, SX = ACC + 8 * WAVE;   // M-chunk
+    static constexpr int SIZE = (4 + 2 * NC) * WAVE > (NC + 3 + 16) * WAVE ? (4 + 2 * NC) * WAVE : (NC + 3 + 16) * WAVE;
 };
-__device__ __forceinline__ int role_gather_row_wave(int kk) { return kk < 2 ? 0 : kk == 2 || kk == 6 ? 1 : kk == 3 || kk == 7 ? 2 : 3; }
+__device__ __forceinline__ int role_gather_row_wave(int kk) { return 1 + kk % 3; }     // rows of a lane by waves 1, 2, 3, 1, 2, 3, 1, 2
+// ... and, before the wait for the tiles (but after the previous step's roles are done), the rows' spatial effects at the
+// current position for the same rows: 8 more loads past the L1 that wave 0 no longer issues on its way to the wait
+template <int NTC>
+__device__ __forceinline__ void role_pregather(const Dims &d, const double *spr, int bx, int wv, int lane, double *g) {
+    constexpr int NC = NTC > 0 ? NTC : CT_MAXC;
+    using G = RoleGather<NC>;
+    const int ntc = NTC > 0 ? NTC : d.ntc;
+    if (bx < ntc || d.chunked != 1) return;
+    const int nrow = (d.M + WAVE - 1) / WAVE;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        if (role_gather_row_wave(kk) != wv || kk >= nrow) continue;
+        const int mm = lane + kk * WAVE;
+        const bool on = mm < d.M;
+        const double sv_ = __hip_atomic_load(spr + (on ? mm : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g[G::SX + kk * WAVE + lane] = on ? sv_ : 0.0;
+    }
+}
 template <int NTC>
 __device__ __forceinline__ void role_gather(const Dims &d, const Work &w, int b, int bx, int wv, int lane, double *g) {
     auto LDP = [](const double *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -904,7 +926,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Work &w, int b,
 template <int NTC, bool COH, bool PERS = false, typename Wait>
 __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
                                                const Chains &ch, int par, int bx, int b, Wait wait, int lane_in = -1,
-                                               unsigned long long *probe = nullptr, double *gbuf = nullptr) {
+                                               unsigned long long *probe = nullptr, double *gbuf = nullptr, int traj = 0) {
 #ifdef LEAP_STAMPS
 #define CPROBE(k) do { asm volatile("s_nop 0" ::: "memory"); if (probe && threadIdx.x == 0) probe[(k) < 8 ? (k) : 2 * 128 + (k) - 8] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -925,9 +947,18 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
     // on something defined in the loop, and the compiler cannot hoist -- and then spill -- a few dozen 64-bit addresses)
     const int lane = PERS ? lane_in : (int)threadIdx.x;
     double *q = ch.q + (size_t)b * d.Pp, *p = ch.p + (size_t)b * d.Pp;
+    const double *qs0 = ch.q0 + (size_t)b * d.Pp;          // the trajectory's start point (== q before the first step; nobody writes it here)
     const double *var = ch.var + (size_t)b * d.Pp;
     double *sc = w.scal + (size_t)b * NSCAL;
     const double eps = ch.hs[(size_t)b * NHS + HS_EPS];
+    // traj (k_leap with the trajectory's end points folded in): 1 = this is the FIRST step of the trajectory -- what
+    // k_hmc_step<0> does in the multi-launch forms: the momentum is drawn here (same Philox slots), the kick is half a step
+    // and the kinetic energy's / log-probability's parts are left for the accept test.  Everything of the start point is
+    // read from Chains::q0 (and psi, sigma, the sigmoids formed again from it): the other roles of this step are already
+    // writing the next position to q and the scalar block.  2 = the step after it, whose first T-chunk adds the parts up
+    // (every role of step one has finished)
+    const bool first = PERS && traj == 1;
+    const double kick = first ? 0.5 * eps : eps;
     const int oT = 6 - 1, oM = 6 + T - 1;
     const double *TS = w.TS + (size_t)b * ntile * 4;
     const double *gr = w.gst + ((size_t)b * 2 + par) * GST_N;
@@ -938,33 +969,91 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const bool own = t >= 1 && t < T;
         ltab[lane] = c.logtab[lane];
         ltab[lane + WAVE] = c.logtab[lane + WAVE];
-        const double alpha = own ? LDQ(q + oT + t) : 0.0, pm = own ? LDQ(p + oT + t) : 0.0, v = own ? var[oT + t] : 0.0;
+        const double alpha = own ? LDQ((first ? qs0 : q) + oT + t) : 0.0, v = own ? var[oT + t] : 0.0;
         const double wd_t = c.wd[t];
-        const double a0 = LDQ(gr + 5), g0 = LDQ(gr + 3), g1 = LDQ(gr + 4), pa0 = LDQ(gr + 11), pg0 = LDQ(gr + 9), pg1 = LDQ(gr + 10);
         const double va0 = var[5], vg0 = var[3], vg1 = var[4];
+        double pm, a0, g0, g1, pa0, pg0, pg1;
+        RngKey key{};
+        if (first) {
+            key = rng_key(s, ch, b);
+            pm = own ? momentum_normal(key, oT + t) / sqrt(v) : 0.0;
+            a0 = qs0[5]; g0 = qs0[3]; g1 = qs0[4];
+            pa0 = momentum_normal(key, 5) / sqrt(va0); pg0 = momentum_normal(key, 3) / sqrt(vg0); pg1 = momentum_normal(key, 4) / sqrt(vg1);
+        } else {
+            pm = own ? LDQ(p + oT + t) : 0.0;
+            a0 = LDQ(gr + 5); g0 = LDQ(gr + 3); g1 = LDQ(gr + 4); pa0 = LDQ(gr + 11); pg0 = LDQ(gr + 9); pg1 = LDQ(gr + 10);
+        }
         // V at the chunk ends, the chunk sums of the current position (chunk = lane)
         double vend[NC];
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) vend[cc] = cc < ntc ? w.Vt[(size_t)b * d.Tp + cc * WAVE + WAVE - 1] : 0.0;
         const double *ctr = w.CT + (((size_t)b * 2 + par) * CT_MAXC) * 4;
-        const double cta_l = lane < ntc ? LDQ(ctr + lane * 4) : 0.0, ctvp_l = lane < ntc ? LDQ(ctr + lane * 4 + 1) : 0.0,
-                     ctva_l = lane < ntc ? LDQ(ctr + lane * 4 + 2) : 0.0;
+        double cta_l = 0.0, ctvp_l = 0.0, ctva_l = 0.0, cg0_l = 0.0, cg1_l = 0.0;
         // I->R gradient (gamma0, gamma1): the chunks' parts, left by the previous step (Work::CG) -- ntc pairs instead
         // of one series evaluation per day of the whole series in every chunk
         const double *cgr = w.CG + (((size_t)b * 2 + par) * CT_MAXC) * 2;
-        const double cg0_l = lane < ntc ? LDQ(cgr + lane * 2) : 0.0, cg1_l = lane < ntc ? LDQ(cgr + lane * 2 + 1) : 0.0;
         const double kir_t = t < T ? w.Kir[(size_t)b * d.Tp + t] : 0.0, dir_t = t < T ? w.Dir[(size_t)b * d.Tp + t] : 0.0;
+        if (!first) {
+            if (lane < ntc) { cta_l = LDQ(ctr + lane * 4); ctvp_l = LDQ(ctr + lane * 4 + 1); ctva_l = LDQ(ctr + lane * 4 + 2); }
+            if (lane < ntc) { cg0_l = LDQ(cgr + lane * 2); cg1_l = LDQ(cgr + lane * 2 + 1); }
+        }
         // The I->R part of the step needs nothing of this step's tiles -- gamma0 and gamma1 move by the chunk parts the
         // previous step left (Work::CG) -- so all of it (two wave sums, the new rates, the series, two more wave sums: half of
         // the role's dependent operations) runs BEFORE the wait, under the tile phase.  Same operations, same results.
         CPROBE(10);                                         // entry loads issued
         if (PERS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the workgroup's other waves are alive there: no s_barrier)
         else lds_barrier();                                // ltab (single wave: orders the LDS writes)
+        if (first) {
+            // nobody left the chunk sums of the start point: this wave forms them -- of the chunks before its own (alpha, v p,
+            // v alpha: the momenta of those chunks are drawn again here, Philox is a counter) and, for all chunks, the parts of
+            // the I->R term's gradient and the term itself (the start point's log-probability, for the accept test).  All of
+            // it before the wait for the tiles.
+            for (int cc = 0; cc < ci; ++cc) {
+                const int tt = cc * WAVE + lane;
+                const bool on = tt >= 1 && tt < T;
+                const double al = on ? qs0[oT + tt] : 0.0, vv = on ? var[oT + tt] : 0.0;
+                const double pp = on ? momentum_normal(key, oT + tt) / sqrt(vv) : 0.0;
+                const double sa = wave_sum(al), svp = wave_sum(vv * pp), sva = wave_sum(vv * al);
+                if (lane == cc) { cta_l = sa; ctvp_l = svp; ctva_l = sva; }
+            }
+            double irl = 0.0;
+            for (int cc = 0; cc < ntc; ++cc) {
+                const int tt = cc * WAVE + lane;
+                double x0 = 0.0, x1 = 0.0, xl = 0.0;
+                if (tt < T) {
+                    const double rr_ = exp(g0 + g1 * c.wd[tt]);
+                    const double kk_ = w.Kir[(size_t)b * d.Tp + tt], dd_ = w.Dir[(size_t)b * d.Tp + tt];
+                    double L, inv;
+                    l1me_inv_wide(rr_ * d.dt, L, inv, ltab);
+                    const double grr = d.dt * ((kk_ != 0.0 ? kk_ * inv : 0.0) - dd_);
+                    x0 = grr * rr_; x1 = grr * rr_ * c.wd[tt];
+                    xl = (kk_ != 0.0 ? kk_ * L : 0.0) - dd_ * (rr_ * d.dt);
+                }
+                const double s0_ = wave_sum(x0), s1_ = wave_sum(x1);
+                irl += wave_sum(xl);
+                if (lane == cc) { cg0_l = s0_; cg1_l = s1_; }
+            }
+            if (ci == 0 && lane == 0) ch.irl0[b] = irl;
+        }
+        if (PERS && traj == 2 && ci == 0) {
+            // the step after the first: the start point's kinetic energy and log-probability from the parts the first step's
+            // roles and tiles left (all of them have finished: the caller waited for that)
+            const int nroles = ntc + d.Mp / WAVE;
+            const double k0 = wave_sum(lane < nroles ? LDQ(ch.k0part + (size_t)b * 32 + lane) : 0.0);
+            double lk = 0.0;
+            for (int i = lane; i < ntile; i += WAVE) lk += LDP(w.Lpart0 + (size_t)b * ntile + i);
+            lk = wave_sum(lk);
+            if (lane == 0) {
+                double *hs = ch.hs + (size_t)b * NHS;
+                hs[HS_LP0] = (lk + LDQ(ch.irl0 + b)) + sc[SC_PRIOR] + sc[SC_JAC];
+                hs[HS_K0] = k0;
+            }
+        }
         const double gg0 = wave_sum(cg0_l), gg1 = wave_sum(cg1_l);
         if (probe) { asm volatile("" :: "v"(gg0), "v"(gg1)); }
         CPROBE(11);                                         // entry loads back, two wave sums
-        const double pg0n = pg0 + eps * (gg0 - g0 / 1.0e4), g0n = g0 + eps * vg0 * pg0n;
-        const double pg1n = pg1 + eps * (gg1 - g1 / 1.0e4), g1n = g1 + eps * vg1 * pg1n;
+        const double pg0n = pg0 + kick * (gg0 - g0 / 1.0e4), g0n = g0 + eps * vg0 * pg0n;
+        const double pg1n = pg1 + kick * (gg1 - g1 / 1.0e4), g1n = g1 + eps * vg1 * pg1n;
         double ng0p = 0.0, ng1p = 0.0, rnew = 0.0;
         if (t < T) {
             rnew = exp(g0n + g1n * wd_t);
@@ -1052,7 +1141,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             p_all += bs[cc];
             lat += bs[cc];
         }
-        p_pre = eps * eps * p_pre + (lane < ci ? cta_l + eps * (ctvp_l - eps * PREC * ctva_l) : 0.0);
+        p_pre = eps * kick * p_pre + (lane < ci ? cta_l + eps * (ctvp_l - kick * PREC * ctva_l) : 0.0);
         if (probe) { asm volatile("" :: "v"(col), "v"(p_pre)); }
         CPROBE(5);                                          // loads back
         const double later = wave_sum(p_later), allB = wave_sum(p_all), pre = wave_sum(p_pre);
@@ -1061,9 +1150,14 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         // this chunk's entries
         const double insuf = wave_incl_suffix_scan(col, lane);
         const double g = own ? (insuf + later) - alpha * PREC : 0.0;
-        const double pn = own ? pm + eps * g : 0.0;
+        const double pn = own ? pm + kick * g : 0.0;
         const double an = own ? alpha + eps * v * pn : 0.0;
-        const double pa0n = pa0 + eps * (allB - a0 / 100.0), a0n = a0 + eps * va0 * pa0n;
+        const double pa0n = pa0 + kick * (allB - a0 / 100.0), a0n = a0 + eps * va0 * pa0n;
+        if (first) {
+            double kin = wave_sum(own ? 0.5 * v * pm * pm : 0.0);
+            if (ci == 0) kin += (0.5 * vg0 * pg0 * pg0 + 0.5 * vg1 * pg1 * pg1) + 0.5 * va0 * pa0 * pa0;
+            if (lane == 0) ch.k0part[(size_t)b * 32 + bx] = kin;
+        }
         const double a_new = a0n + pre + wave_incl_scan(an, lane);
         if (probe) { asm volatile("" :: "v"(a_new)); }
         CPROBE(7);                                          // two scans
@@ -1090,13 +1184,31 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         // ------------------------------------------------------------------ M-chunk
         const int ci = bx - ntc, m = ci * WAVE + lane;
         const bool own = m < M;
-        const double *spr = w.sp + ((size_t)b * 2 + par) * d.Mp;
+        // (first step of a folded trajectory: the spatial effects of the start point are q's own)
+        const double *spr = first ? qs0 + oM : w.sp + ((size_t)b * 2 + par) * d.Mp;
         double *spw = w.sp + ((size_t)b * 2 + (par ^ 1)) * d.Mp;
-        const double sm = own ? LDQ(q + oM + m) : 0.0, pm = own ? LDQ(p + oM + m) : 0.0, v = own ? var[oM + m] : 0.0;
+        const double sm = own ? LDQ((first ? qs0 : q) + oM + m) : 0.0, v = own ? var[oM + m] : 0.0;
         const double lm = own ? c.la[m] : 0.0, inN = own ? c.invN[m] : 0.0;
-        const double u0 = LDQ(gr + 0), u1 = LDQ(gr + 1), beta = LDQ(gr + 2), p0 = LDQ(gr + 6), p1 = LDQ(gr + 7), p2 = LDQ(gr + 8);
-        const double psi = LDQ(gr + 12), sig = LDQ(gr + 13), s0 = LDQ(gr + 14), s1 = LDQ(gr + 15);
         const double v0 = var[0], v1 = var[1], v2 = var[2];
+        double pm, u0, u1, beta, p0, p1, p2, psi, sig, s0, s1;
+        if (first) {
+            const RngKey key = rng_key(s, ch, b);
+            pm = own ? momentum_normal(key, oM + m) / sqrt(v) : 0.0;
+            u0 = qs0[0]; u1 = qs0[1]; beta = qs0[2];
+            p0 = momentum_normal(key, 0) / sqrt(v0); p1 = momentum_normal(key, 1) / sqrt(v1); p2 = momentum_normal(key, 2) / sqrt(v2);
+            // psi, sigma and the two sigmoids of the start point, as every kernel that leaves them in the scalar block forms them
+            // (that block is being rewritten by the first M-chunk of this very step)
+            const double e0_ = 2.220446049250313e-16;
+            const double ux_ = lane == 0 ? u0 : u1;
+            const double spx_ = softplus(ux_);
+            const double sgx_ = cold_exp(ux_ - spx_);
+            psi = lane_value(spx_, 0) + e0_; sig = lane_value(spx_, 1) + e0_;
+            s0 = lane_value(sgx_, 0); s1 = lane_value(sgx_, 1);
+        } else {
+            pm = own ? LDQ(p + oM + m) : 0.0;
+            u0 = LDQ(gr + 0); u1 = LDQ(gr + 1); beta = LDQ(gr + 2); p0 = LDQ(gr + 6); p1 = LDQ(gr + 7); p2 = LDQ(gr + 8);
+            psi = LDQ(gr + 12); sig = LDQ(gr + 13); s0 = LDQ(gr + 14); s1 = LDQ(gr + 15);
+        }
         double Qs = 0.0;                                   // (Q s)_m at the current position
         if (own) {
             if (c.qw > 0 && c.qw <= 8) {
@@ -1127,9 +1239,9 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                 const int mm = lane + kk * WAVE;
                 const bool on = mm < M;
                 const int mc = on ? mm : 0;
-                const double lv_ = c.la[mc], sv_ = LDQ(spr + mc);
+                const double lv_ = c.la[mc];
                 lxp[kk] = on ? lv_ : 0.0;
-                sxp[kk] = on ? sv_ : 0.0;
+                sxp[kk] = 0.0;                              // (from the helper waves, through LDS: role_pregather)
             }
         }
         wait();
@@ -1149,6 +1261,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                 for (int kk = 0; kk < RPL; ++kk)
                     if (kk < nrow) {
                         const double acc = gbuf[G::ACC + kk * WAVE + lane];
+                        sxp[kk] = gbuf[G::SX + kk * WAVE + lane];
                         rl = fma(lxp[kk], acc, rl); rs = fma(sxp[kk], acc, rs);
                     }
             }
@@ -1210,11 +1323,16 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         }
         ps = wave_sum(ps); rl = wave_sum(rl); rs = wave_sum(rs);
         const double g = own ? sig * R - Qs : 0.0;
-        const double pn = pm + eps * g;
+        const double pn = pm + kick * g;
         const double sn = sm + eps * v * pn;
-        const double p0n = p0 + eps * ((ps + 2.0 / psi - 10.0) * s0 + (1.0 - s0)), u0n = u0 + eps * v0 * p0n;
-        const double p1n = p1 + eps * ((rs - sig / 0.01) * s1 + (1.0 - s1)), u1n = u1 + eps * v1 * p1n;
-        const double p2n = p2 + eps * (rl - beta), betan = beta + eps * v2 * p2n;
+        const double p0n = p0 + kick * ((ps + 2.0 / psi - 10.0) * s0 + (1.0 - s0)), u0n = u0 + eps * v0 * p0n;
+        const double p1n = p1 + kick * ((rs - sig / 0.01) * s1 + (1.0 - s1)), u1n = u1 + eps * v1 * p1n;
+        const double p2n = p2 + kick * (rl - beta), betan = beta + eps * v2 * p2n;
+        if (first) {
+            double kin = wave_sum(own ? 0.5 * v * pm * pm : 0.0);
+            if (ci == 0) kin += (0.5 * v0 * p0 * p0 + 0.5 * v1 * p1 * p1) + 0.5 * v2 * p2 * p2;
+            if (lane == 0) ch.k0part[(size_t)b * 32 + bx] = kin;
+        }
         // both softplus in one pass: lane 0 takes u0, the other lanes u1
         const double e0 = 2.220446049250313e-16;
         const double ux = lane == 0 ? u0n : u1n;
@@ -1410,9 +1528,13 @@ __device__ __forceinline__ void leap_wait(const unsigned long long *flag, unsign
 // are materialised for.
 template <int TSM, int NST>
 __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s, const Chains &ch,
-                                          int bx, int byg, int bz, int par0, int nsteps, unsigned long long step_base) {
+                                          int bx, int byg, int bz, int par0, int nsteps, unsigned long long step_base,
+                                          unsigned long long role_base, int fold) {
+    // fold (the trajectory's end points inside this launch): bit 0 = the first of the nsteps evaluations is the gradient at the
+    // START point (the roles' first step draws the momentum: k_hmc_step<0>'s work), bit 1 = the last one is the gradient at the END
+    // point, for k_hmc_step<2> (no role follows it).  At those two the S->E term's value is summed as well (Lpart0 / Lpart).
     __shared__ double colbuf[NST][4][WAVE];
-    __shared__ double psibuf[NST][4][WAVE];
+    __shared__ double psibuf[NST][4][WAVE], llbuf[NST][4][WAVE];
     __shared__ double rowbuf[NST][4 * SE_RW * SE_RS];
     __shared__ double rlbuf[TSM == 2 ? NST : 1][4][WAVE], rsbuf[TSM == 2 ? NST : 1][4][WAVE];
     __shared__ double2 ltab[LDSTAB_N];
@@ -1469,7 +1591,7 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             const bool fetch = wu == 0 || wu == 1 || wu == 3 || (ts_rows && wu == 2);
             if (it > 0 && fetch) {
                 __builtin_amdgcn_s_sleep(LEAP_BACKOFF);
-                leap_wait(flag2, step_base + (unsigned long long)it, ch.late + ch.late_fatal + b);
+                leap_wait(flag2, role_base + (unsigned long long)it, ch.late + ch.late_fatal + b);
             }
             if (threadIdx.x == 0) { LSTAMP_MIN(0); LSTAMP_MAX(1); }
             LPROBE(0);
@@ -1479,7 +1601,14 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             } else if (wu == 1) {
                 if (lane < NST * SE_TM) tabbuf[TB_EB + lane] = LDP(w.eb + (size_t)b * d.Mp + mg + lane);
             } else if (wu == 2) {
-                if (ts_rows && lane < NST * SE_TM) tabbuf[TB_SP + lane] = LDP(w.sp + ((size_t)b * 2 + par) * d.Mp + mg + lane);
+                // (the first evaluation of a folded trajectory: the start point's spatial effects are q's own)
+                if (ts_rows && lane < NST * SE_TM) {
+                    const int row = mg + lane;
+                    double v_;
+                    if ((fold & 1) && it == 0) v_ = row < d.M ? LDP(ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1 + row) : 0.0;
+                    else v_ = LDP(w.sp + ((size_t)b * 2 + par) * d.Mp + row);
+                    tabbuf[TB_SP + lane] = v_;
+                }
             } else {
                 if (lane == 0) tabbuf[TB_PSI] = LDP(w.scal + (size_t)b * NSCAL + SC_PSI);
             }
@@ -1491,6 +1620,7 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
         const double psi = tabbuf[TB_PSI];
         const double ea_t = tabbuf[lane];
         const double psiW = psi * Wt;
+        const bool with_ll = ((fold & 1) && it == 0) || ((fold & 2) && it == nsteps - 1);       // uniform
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             double eb[SE_RW], ts_s[SE_RW];
@@ -1500,14 +1630,14 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
                 ts_s[r] = ts_rows ? tabbuf[TB_SP + st * SE_TM + wave * SE_RW + r] : 0.0;
             }
             double *myrow = rowbuf[st] + wave * SE_RW * SE_RS;
-            double gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0;
+            double gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0, ll = 0.0;
             // the four cells side by side (se_cells: se_tile's own evaluation).  Only the GRADIENT of the S->E term drives a
             // leapfrog step: the term's value (and with it log(1 - e^-r), a third of a cell's instructions) is needed at the
-            // trajectory's end points alone, which k_se evaluates -- L is left unused here and the compiler drops its chain
+            // trajectory's end points alone (with_ll) -- everywhere else the series' logarithm is dead code on the taken path
             double Id[SE_RW], ee[SE_RW], lam0[SE_RW], rr[SE_RW], L[SE_RW], inv[SE_RW];
 #pragma unroll
             for (int r = 0; r < SE_RW; ++r) Id[r] = (double)Ii[st][r];
-            se_cells<SE_RW>(ea_t, eb, Id, psiW, F[st], d.rate_floor, d.dt, ltab, sk, ee, lam0, rr, L, inv);
+            se_cells<SE_RW, false>(ea_t, eb, Id, psiW, F[st], d.rate_floor, d.dt, ltab, sk, ee, lam0, rr, L, inv);
 #pragma unroll
             for (int r = 0; r < SE_RW; ++r) {
                 const double kse = (double)ki[st][r], snk = (double)(si[st][r] - ki[st][r]);
@@ -1523,6 +1653,15 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
                 gpsi += gl * ee[r] * Wt * F[st][r];
             }
             psibuf[st][wave][lane] = gpsi;
+            if (with_ll) {                                       // the trajectory's end points only: a cold block, behind the hot one
+                se_cells_L<SE_RW>(rr, ltab, sk, L);
+#pragma unroll
+                for (int r = 0; r < SE_RW; ++r) {
+                    const double kse = (double)ki[st][r], snk = (double)(si[st][r] - ki[st][r]);
+                    ll += (kse != 0.0 ? kse * L[r] : 0.0) - snk * rr[r];
+                }
+                llbuf[st][wave][lane] = ll;
+            }
             colbuf[st][wave][lane] = colacc;
             {
                 constexpr int LPR = WAVE / SE_RW;
@@ -1546,7 +1685,10 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             const int by = byg * NST + st;
             const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
             if (wave == 0) {
-                // (no log-likelihood partial: see above)
+                if (with_ll) {                                   // the end points only
+                    const double v = wave_sum((llbuf[st][0][lane] + llbuf[st][1][lane]) + (llbuf[st][2][lane] + llbuf[st][3][lane]));
+                    if (lane == 0) (((fold & 1) && it == 0) ? w.Lpart0 : w.Lpart)[tile] = v;
+                }
             } else if (wave == 1) {
                 const double v = wave_sum((psibuf[st][0][lane] + psibuf[st][1][lane]) + (psibuf[st][2][lane] + psibuf[st][3][lane]));
                 if (lane == 0) w.Ppart[tile] = v;
@@ -1595,14 +1737,15 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
 constexpr int leap_waves_per_simd(int nst) { return nst == 1 ? 5 : 3; }
 template <int TSM, int NTC, int NST>
 __global__ __launch_bounds__(256, NTC == 12 ? (leap_waves_per_simd(NST) < 3 ? leap_waves_per_simd(NST) : 3) : leap_waves_per_simd(NST))
-void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nsteps, unsigned long long step_base) {
+void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nsteps, unsigned long long step_base,
+            unsigned long long role_base, int fold) {
     const int nwg = d.ntc * d.nmt / NST, n_tiles = nwg * d.aff_nb;   // tile workgroups per chain: NST gradient tiles each
     const int nroles = d.ntc + d.Mp / WAVE;
     if ((int)blockIdx.x < n_tiles) {
         int bz, tile;
         xcd_affine(blockIdx.x, nwg, d.aff_nb, bz, tile);
         if (d.nlive > 0 && bz >= d.nlive) return;      // a chain of the layout that does not exist
-        leap_tile<TSM, NST>(d, c, w, s, ch, tile % d.ntc, tile / d.ntc, bz, par0, nsteps, step_base);
+        leap_tile<TSM, NST>(d, c, w, s, ch, tile % d.ntc, tile / d.ntc, bz, par0, nsteps, step_base, role_base, fold);
         return;
     }
     // a role: wave 0 runs it, the workgroup's other three waves share its loads of the tiles' partial sums (role_gather)
@@ -1618,12 +1761,14 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
     unsigned long long *cnt2 = LEAP_CNT2(b);
     const unsigned long long *flag2 = LEAP_FLAG2(b, role & (LEAP_NSH - 1));
     unsigned *late = ch.late + ch.late_fatal + b;
-    for (int it = 0; it < nsteps; ++it) {
+    const int nrole_steps = nsteps - ((fold & 2) ? 1 : 0);      // nobody follows the end point's gradient here: k_hmc_step<2> does
+    for (int it = 0; it < nrole_steps; ++it) {
         // nothing of a role lives across the steps: without this the compiler hoists the step-invariant loads of the role
         // (variances, V(t), the I->R statistics, CAR rows ...) out of the loop and spills 500+ bytes per lane to hold them
         asm volatile("" ::: "memory");
         const int par = par0 ^ (it & 1);
-        const unsigned long long stepno = step_base + (unsigned long long)(it + 1);
+        const unsigned long long stepno = step_base + (unsigned long long)(it + 1);      // what the tiles' flags show
+        const unsigned long long rstep = role_base + (unsigned long long)(it + 1);       // what the roles' flag will show
         int lane_op = lane_w;
         asm volatile("" : "+v"(lane_op));
         auto wait_tiles = [&] {
@@ -1635,13 +1780,21 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
             }
         };
         if (wv != 0) {
+            // the helper waves: the rows' spatial effects of the current position once the previous step's roles are done
+            // (the first step of a folded trajectory reads q itself), then the partial sums once the tiles are in
+            if (it > 0) leap_wait(flag2, role_base + (unsigned long long)it, late);
+            {
+                const bool first_ = (fold & 1) && it == 0;
+                const double *spr_ = first_ ? ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1 : w.sp + ((size_t)b * 2 + par) * d.Mp;
+                role_pregather<NTC>(d, spr_, role, wv, lane_op, gbuf);
+            }
             wait_tiles();
             role_gather<NTC>(d, w, b, role, wv, lane_op, gbuf);
             lds_barrier();                                       // wave 0 is at its own, inside the role
             continue;
         }
         // what the roles of the previous step wrote (chunk sums, global parameters, spatial effects, q and p)
-        if (it > 0) leap_wait(flag2, step_base + (unsigned long long)it, late);
+        if (it > 0) leap_wait(flag2, role_base + (unsigned long long)it, late);
         RPROBE(0);                                               // the previous step's roles are done
         hmc_chunk_role<NTC, true, true>(d, c, w, s, ch, par, role, b, [&] {
             wait_tiles();
@@ -1653,19 +1806,44 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
 #else
         nullptr,
 #endif
-        gbuf);
+        gbuf, (fold & 1) ? (it == 0 ? 1 : it == 1 ? 2 : 0) : 0);
         RPROBE(2);                                               // stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this role's stores are in the XCD's L2
         RPROBE(3);
         {
             unsigned long long old = 0ull;
             if (threadIdx.x == 0) old = __hip_atomic_fetch_add(cnt2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = __builtin_amdgcn_readfirstlane((int)(old + 1 == stepno * (unsigned long long)nroles)) != 0;
+            const bool last = __builtin_amdgcn_readfirstlane((int)(old + 1 == rstep * (unsigned long long)nroles)) != 0;
             if (last && threadIdx.x < LEAP_NSH)                  // the step's last role: eight copies of the flag, one store
-                __hip_atomic_store(LEAP_FLAG2(b, threadIdx.x), stepno, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(LEAP_FLAG2(b, threadIdx.x), rstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (threadIdx.x == 0) { LSTAMP_MIN(6); LSTAMP_MAX(7); }
             RPROBE(4);                                           // counted in
         }
+    }
+}
+
+// V(t) = sum_{s=1..t} var[alpha_t[s-1]] (Work::Vt), which the chunked leapfrog steps need and k_hmc_step<0> writes on its
+// way: with the trajectory's first step folded into k_leap somebody else has to, whenever the variances change (set_kernel,
+// set_adaptation, and every sweep of a mass-adaptation window).  One wave per chain; the additions in the order of
+// k_hmc_step<0>'s block scan (blocks of HB days, wave by wave), so that the table is the same to the bit.
+__global__ __launch_bounds__(WAVE) void k_vt(Dims d, Work w, Chains ch) {
+    const int b = d.b0 + blockIdx.x, lane = threadIdx.x;
+    const double *var = ch.var + (size_t)b * d.Pp;
+    const int oT = 6 - 1;
+    double vcarry = 0.0;
+    for (int t0 = 0; t0 < d.Tp; t0 += HB) {
+        double base = 0.0, tot = 0.0;
+        for (int wv = 0; wv < HWV; ++wv) {
+            const int t = t0 + wv * WAVE + lane;
+            const double vv = (t >= 1 && t < d.T) ? var[oT + t] : 0.0;
+            const double inc = wave_incl_scan(vv, lane);
+            const double excl = base + inc - vv;
+            if (t < d.Tp) w.Vt[(size_t)b * d.Tp + t] = vcarry + excl + vv;
+            const double x = lane_value(inc, 63);
+            tot += x;
+            base += x;
+        }
+        vcarry += tot;
     }
 }
 

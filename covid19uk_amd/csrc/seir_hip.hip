@@ -963,7 +963,10 @@ struct seir_sampler {
     int leap_occ[2][3][2];        // workgroups of k_leap<TSM, NTC, NST> the chip holds at once (occupancy query, cached; -1: not asked yet)
     // seir_sampler_time_leapfrog: HIP events around the inner leapfrog steps of each sweep while it is on
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after)
-    int prof_i = -1, prof_launches = 0;  // next pair to record (-1: off); launches of the section in the last sweep
+    int prof_i = -1, prof_launches = 0, prof_evals = 0;  // next pair to record (-1: off); launches / gradient evaluations of the section in the last sweep
+    bool hmc_fold = true;         // hmc_mode 0: the trajectory's first step and both end-point gradients inside k_leap as well
+    bool vt_dirty = true;         // Work::Vt does not match Chains::var (set_kernel / set_adaptation / creation)
+    unsigned long long leap_rsteps = 0;  // steps the ROLES of k_leap have done over all launches (the tiles do one more per folded launch)
     unsigned long long leap_steps = 0;   // leapfrog steps done by all k_leap launches so far (what Chains::leap's flags show)
     bool xcd_local = false;       // blocks with the same id mod 8 share an XCD (k_xcc_probe at creation)
     unsigned long long tail_count = 0;   // tiles per chain counted in by all k_se_chunk launches so far (Chains::tail)
@@ -1009,7 +1012,7 @@ extern "C" void seir_sampler_destroy(seir_sampler *s) {
     Work &w = s->ctx->w;
     for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
     w.rowtot = w.rngtot = nullptr;
-    w.TS = w.sp = w.gst = w.Vt = w.acur = w.rirc = w.CT = w.CG = nullptr;
+    w.TS = w.sp = w.gst = w.Vt = w.acur = w.rirc = w.CT = w.CG = w.Lpart0 = nullptr;
     delete s;
 }
 
@@ -1030,8 +1033,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
     if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
-    if (ds->moves_mode < 0 || ds->moves_mode > 3 || ds->hmc_mode < 0 || ds->hmc_mode > 3)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..3, hmc_mode 0..3");
+    if (ds->moves_mode < 0 || ds->moves_mode > 3 || ds->hmc_mode < 0 || ds->hmc_mode > 4)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..3, hmc_mode 0..4");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
@@ -1055,8 +1058,9 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     s->use_graph = ds->use_graph != 0;
     s->pair_debug = ds->debug_pair;
     s->hmc_chunked = ds->hmc_mode != 1;
-    s->hmc_tail = ds->hmc_mode == 0 || ds->hmc_mode == 3;
-    s->hmc_leap = ds->hmc_mode == 0;
+    s->hmc_tail = ds->hmc_mode == 0 || ds->hmc_mode == 3 || ds->hmc_mode == 4;
+    s->hmc_leap = ds->hmc_mode == 0 || ds->hmc_mode == 4;
+    s->hmc_fold = ds->hmc_mode == 0;
     for (auto &a : s->leap_occ) for (auto &b2 : a) for (int &v : b2) v = -1;
     s->moves_mode = ds->moves_mode;
     c.disable_mask = ds->disable_mask;
@@ -1078,6 +1082,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(w.rowtot, (size_t)ctx->Bmax * 2 * d.Mp);
     S_ALLOC(w.rngtot, (size_t)ctx->Bmax * 2 * d.Mp);
     S_ALLOC(w.TS, (size_t)ctx->Bmax * d.nmt * d.ntc * 4);
+    S_ALLOC(w.Lpart0, (size_t)ctx->Bmax * d.nmt * d.ntc);
     S_ALLOC(w.sp, (size_t)ctx->Bmax * 2 * d.Mp);
     S_ALLOC(w.gst, (size_t)ctx->Bmax * 2 * GST_N);
     S_ALLOC(w.Vt, (size_t)ctx->Bmax * d.Tp);
@@ -1098,6 +1103,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     ch.late_fatal = B;
     S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
     S_ALLOC(ch.leap, (size_t)B * LEAP_CH);
+    S_ALLOC(ch.k0part, (size_t)B * 32);
+    S_ALLOC(ch.irl0, (size_t)B);
     S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
     S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
     S_ALLOC(ch.hand2, (size_t)B);
@@ -1189,6 +1196,9 @@ extern "C" int seir_sampler_set_state(seir_sampler *s, const double *u, const do
         if (!(events[i] >= 0.0 && events[i] < 2147483648.0 && events[i] == std::floor(events[i])))
             return fail(SEIR_ERR_INVALID, "events[%zu]=%g is not a non-negative integer count", i, events[i]);
     HIP_TRY(hipMemcpyAsync(s->ch.q, u, sizeof(double) * B * d.P, hipMemcpyHostToDevice, ctx->stream));
+    // Chains::q0 = the position at the start of the next trajectory, kept equal to q between trajectories (k_hmc_step<2>
+    // leaves it so): the folded first step reads the start point from it while its roles already write the next one to q
+    HIP_TRY(hipMemcpyAsync(s->ch.q0, u, sizeof(double) * B * d.P, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(s->ev_stage, events, sizeof(double) * B * d.M * d.T * 3, hipMemcpyHostToDevice,
                            ctx->stream));
     hipLaunchKernelGGL(k_import_events, dim3(1024), dim3(256), 0, ctx->stream, d, ctx->w, s->ev_stage, B);
@@ -1249,9 +1259,11 @@ extern "C" int seir_sampler_set_kernel(seir_sampler *s, const double *step_size,
         for (size_t i = 0; i < (size_t)B * d.P; ++i)
             if (!(variance[i] > 0.0)) return fail(SEIR_ERR_INVALID, "variance[%zu] must be positive", i);
         HIP_TRY(hipMemcpy(s->ch.var, variance, sizeof(double) * B * d.P, hipMemcpyHostToDevice));
+        s->vt_dirty = true;
     } else {
         std::vector<double> ones((size_t)B * d.P, 1.0);
         HIP_TRY(hipMemcpy(s->ch.var, ones.data(), sizeof(double) * B * d.P, hipMemcpyHostToDevice));
+        s->vt_dirty = true;
     }
     return 0;
 }
@@ -1311,6 +1323,7 @@ extern "C" int seir_sampler_set_adaptation(seir_sampler *s, int32_t adapt_step, 
         c.target_accept != target)
         drop_graph(s);                               // kernel arguments are baked into the graph
     c.adapt_step = adapt_step; c.adapt_mass = adapt_mass; c.n_adapt = n_adapt; c.target_accept = target;
+    s->vt_dirty = true;                              // the variances may have moved since Work::Vt was last formed (k_vt)
     return 0;
 }
 
@@ -1387,10 +1400,64 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     const bool chunked = s->hmc_chunked && c.L >= 3 && d0.ntc <= CT_MAXC;
     const int ts_mode = chunked ? (d0.Mp <= 512 ? 1 : 2) : 0;   // 1: the M-chunks sum the row partials themselves
     l.d.sp_par = 0;
+    // Is the persistent leapfrog launch (k_leap) usable for this sweep?  (the conditions of k_se_chunk -- XCD placement checked,
+    // one stream, the XCD-affine grid -- and every workgroup of the launch resident at once: its tiles wait for the roles)
+    const int per_roles = d0.ntc + d0.Mp / WAVE, ntile_all = d0.ntc * d0.nmt, nbv_all = (nb + 7) / 8 * 8;
+    bool leap_ok = false;
+    if (chunked && s->hmc_leap && s->hmc_tail && s->xcd_local && s->ngroups == 1 && (l.affinity & 1) && !s->use_graph &&
+        xcd_affinity_applies(ntile_all, nbv_all) && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && c.L >= 3 && d0.nmt <= WAVE &&
+        d0.nmt % 2 == 0) {
+        const int ti = ts_mode - 1, ni = d0.ntc == 1 ? 0 : d0.ntc == 6 ? 1 : 2;
+        if (s->leap_occ[ti][ni][1] < 0) {
+            int occ = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, leap_fn(ts_mode, d0.ntc, 2), 256, 0) != hipSuccess) occ = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            s->leap_occ[ti][ni][1] = occ * cus;                   // workgroups the chip holds at once
+        }
+        leap_ok = (long long)(ntile_all / 2 + per_roles) * nbv_all <= (long long)s->leap_occ[ti][ni][1];
+    }
+    auto launch_leap = [&](int par0, int nsteps, int fold) {
+        Dims df = l.d;
+        df.aff_nb = nbv_all;
+        df.nlive = nbv_all != nb ? nb : 0;
+        df.sp_par = 0;
+        df.chunked = ts_mode;
+        const dim3 gf((unsigned)((ntile_all / 2 + per_roles) * nbv_all));
+        const unsigned long long step_base = s->leap_steps, role_base = s->leap_rsteps;
+        s->leap_steps += (unsigned long long)nsteps;
+        s->leap_rsteps += (unsigned long long)(nsteps - ((fold & 2) ? 1 : 0));
+        void *args[] = {(void *)&df, (void *)&ctx->c, (void *)&ctx->w, (void *)&c, (void *)&s->ch, (void *)&par0, (void *)&nsteps,
+                        (void *)&step_base, (void *)&role_base, (void *)&fold};
+        (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, 2), gf, dim3(256), args, 0, st);
+    };
+    const bool prof0 = s->prof_i >= 0 && (size_t)(2 * s->prof_i + 1) < s->prof_ev.size() && g == 0;
+    const bool fold = leap_ok && s->hmc_fold;
+    if (fold) {
+        // The whole trajectory but its last half kick in ONE launch: gradient at the start point, the first step (momentum
+        // draw, half kick, drift: k_hmc_step<0>'s work, by the chunk roles), the L-1 inner steps, gradient at the end point;
+        // k_hmc_step<2> then closes it (half kick, accept test, adaptation, trace).  L+1 gradient evaluations, L role steps.
+        if (s->vt_dirty || c.adapt_mass) {
+            Dims dv = l.d;
+            hipLaunchKernelGGL(k_vt, dim3(nb), dim3(WAVE), 0, st, dv, ctx->w, s->ch);
+            s->vt_dirty = false;
+        }
+        if (prof0) (void)hipEventRecord(s->prof_ev[2 * s->prof_i], st);
+        launch_leap(1, c.L + 1, 3);
+        if (prof0) {
+            (void)hipEventRecord(s->prof_ev[2 * s->prof_i + 1], st);
+            s->prof_i += 1;
+            s->prof_launches = 1;
+            s->prof_evals = c.L + 1;
+        }
+        l.d.sp_par = c.L & 1 ? 0 : 1;       // the buffer the last role step wrote: steps alternate from buffer 1
+        l.d.chunked = 0;
+        launch_hmc(ctx, l, c, s->ch, 2, /*gather_qs=*/3);
+    } else {
     l.d.chunked = 0;                       // k_se writes tile scalars only ahead of a chunked step
     launch_se<1>(ctx, l, true);
     l.d.chunked = ts_mode;                 // stage 0 hands the trajectory over to the chunk kernel
     launch_hmc(ctx, l, c, s->ch, 0);
+    s->vt_dirty = false;                   // (k_hmc_step<0> writes Work::Vt on its way)
     if (!chunked) {
         for (int i = 1; i < c.L; ++i) {
             launch_se<1>(ctx, l, true);
@@ -1411,41 +1478,14 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const bool tail = s->hmc_tail && s->xcd_local && nbv > 0 && s->ngroups == 1 && (l.affinity & 1) && xcd_affinity_applies(ntile_se, nbv) &&
                           !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && ts_mode != 0;
         // all of them in ONE persistent launch (k_leap: the tiles keep their cells in registers over the steps) when every
-        // workgroup of that launch can be resident at once -- its tiles wait for the roles
-        const bool prof = s->prof_i >= 0 && (size_t)(2 * s->prof_i + 1) < s->prof_ev.size() && g == 0;
+        // workgroup of that launch can be resident at once -- its tiles wait for the roles.  (Reached only when the folded
+        // form above is switched off: the inner steps alone, between k_hmc_step<0> and k_se + k_hmc_step<2>.)
+        const bool prof = prof0;
         if (prof) (void)hipEventRecord(s->prof_ev[2 * s->prof_i], st);
-        bool leap = false;
-        int leap_nst = 1;
-        if (tail && s->hmc_leap && c.L >= 3 && d0.nmt <= WAVE) {     // (role_gather: a lane per row tile)
-            // two gradient tiles per workgroup (one: 96 VGPRs for five waves per SIMD, 176 B of scratch per lane, 18 us per
-            // step; four: 67 KB of LDS, two waves per SIMD, 13.2 us; two: 10.1 us), if that launch fits the chip at once
-            const int ti = ts_mode - 1, ni = d0.ntc == 1 ? 0 : d0.ntc == 6 ? 1 : 2;
-            for (int k = 1; k >= 1 && !leap; --k) {
-                const int nst = 1 << k;
-                if (d0.nmt % nst != 0) continue;
-                if (s->leap_occ[ti][ni][k] < 0) {
-                    const void *fn = leap_fn(ts_mode, d0.ntc, nst);
-                    int occ = 0, cus = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0) != hipSuccess) occ = 0;
-                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-                    s->leap_occ[ti][ni][k] = occ * cus;
-                }
-                if ((long long)(ntile_se / nst + per) * nbv <= (long long)s->leap_occ[ti][ni][k]) { leap = true; leap_nst = nst; }
-            }
-        }
+        const bool leap = leap_ok;
         if (leap) {
-            Dims df = l.d;
-            df.aff_nb = nbv;
-            df.nlive = nbv != nb ? nb : 0;
-            df.sp_par = 0;
-            const int nsteps = c.L - 1;
-            const dim3 gf((unsigned)((ntile_se / leap_nst + per) * nbv));
-            const unsigned long long step_base = s->leap_steps;
-            s->leap_steps += (unsigned long long)nsteps;
-            void *args[] = {(void *)&df, (void *)&ctx->c, (void *)&ctx->w, (void *)&c, (void *)&s->ch, (void *)&par, (void *)&nsteps,
-                            (void *)&step_base};
-            (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, leap_nst), gf, dim3(256), args, 0, st);
-            par = nsteps & 1;
+            launch_leap(par, c.L - 1, 0);
+            par = (c.L - 1) & 1;
         }
         for (int i = 1; i < c.L && !leap; ++i) {
             l.d.sp_par = par;
@@ -1483,11 +1523,13 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             (void)hipEventRecord(s->prof_ev[2 * s->prof_i + 1], st);
             s->prof_i += 1;
             s->prof_launches = leap ? 1 : tail ? c.L - 1 : 2 * (c.L - 1);
+            s->prof_evals = c.L - 1;
         }
     }
     l.d.chunked = 0;
     launch_se<1>(ctx, l, true);
     launch_hmc(ctx, l, c, s->ch, 2, /*gather_qs=*/chunked ? 3 : 0);
+    }   // !fold
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
     // per update [finalize previous | propose] then the log-ratio over the touched cells
     Dims d = l.d;
@@ -1771,7 +1813,7 @@ extern "C" int seir_sampler_time_leapfrog(seir_sampler *s, int32_t sweeps, float
     }
     *mean_ms = (float)(sum / recorded);
     if (launches) *launches = s->prof_launches;
-    if (evals) *evals = s->cfg.L - 1;
+    if (evals) *evals = s->prof_evals;
     return 0;
 }
 

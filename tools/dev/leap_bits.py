@@ -14,7 +14,7 @@ ev = np.stack([case["events"]] * B)
 cfg = dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=2)
 eps = 0.02 if name == "ni11" else 1.2e-5
 out = {}
-for mode, nst in (("chunk-split", 0), ("chunk-launch", 0), ("chunk", 2)):
+for mode, nst in (("chunk-split", 0), ("chunk-launch", 0), ("chunk-leap", 2), ("chunk", 2)):
     with SeirModel(case["cov"], case["init"], max_chains=B) as model:
         with ChainSampler(model, cfg, B, seed=77, trace_capacity=10, hmc=mode, disable=("move/S->E", "move/E->I", "occult/S->E", "occult/E->I")) as s:
             s.set_state(u, ev)
@@ -26,4 +26,5 @@ ref = out[("chunk-split", 0)]
 for k, tr in out.items():
     d = np.abs(tr.theta - ref.theta)
     print(k, "max |dtheta|", d.max(), "at", np.unravel_index(d.argmax(), d.shape), "max |dlogp|", np.abs(tr.hmc["target_log_prob"] - ref.hmc["target_log_prob"]).max(),
-          "accepted", tr.hmc["is_accepted"].ravel().tolist())
+          "max rel |dlogp|", (np.abs(tr.hmc["target_log_prob"] - ref.hmc["target_log_prob"]) / np.abs(ref.hmc["target_log_prob"])).max(),
+          "accepted", tr.hmc["is_accepted"].ravel().astype(int).sum(), "of", tr.hmc["is_accepted"].size)

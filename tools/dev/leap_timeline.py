@@ -41,6 +41,12 @@ with SeirModel(cov, init, max_chains=B) as model:
             np.median(more[..., 0]), np.median(more[..., 2]), np.median(more[..., 3]), np.median(more[..., 4])))                            # [rep, T-chunk 0 / M-chunk 0, step, stamp]
         period = np.median(tiles[:, 0, 2:15, 0] - tiles[:, 0, 1:14, 0])
         print(f"step period (tile 0 past its wait, step to step): median {period:.0f} ns; whole launch ~{period * 15 / 1e3:.1f} us")
+        first = np.median(tiles[:, 0, 1, 0] - tiles[:, 0, 0, 0])
+        d0 = tiles[:, 0, 0, :] - tiles[:, 0, 0, :1]
+        print(f"step 0 (operands from memory, cold code): {first:.0f} ns until tile 0 passes the wait of step 1; inside step 0: " +
+              ", ".join(f"{np.median(d0[:, k]):.0f}" for k in range(7)))
+        r0 = roles[:, :, 0, :] - tiles[:, 0, 0, :1][:, None, :]
+        print("roles in step 0 (T-chunk 0, M-chunk 0), ns after tile 0's first stamp:", np.median(r0, axis=0).round().tolist())
         pn = ["past the wait", "tables in LDS", "cells done", "past middle barrier", "reductions issued", "stores acknowledged", "counted in"]
         for pi, name in enumerate(("tile 0", "tile 77")):
             d = tiles[:, pi, 1:14, :] - tiles[:, pi, 1:14, :1]
