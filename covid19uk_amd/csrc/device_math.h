@@ -221,6 +221,33 @@ __device__ __forceinline__ double log1mexp(double r, const double2 *tab) {
 // same without a table (cold paths)
 __device__ __forceinline__ double log1mexp(double r) { return log(-expm1(-r)); }
 
+// Branch-free forms for code that evaluates a handful of these per lane in one go (own_rows_delta: twelve log-factorials
+// and two log(1 - e^-r) per touched cell).  With the branches of lfact / lbinom each call is a basic block of its own and
+// the calls run one after the other -- ~30 dependent fp64 operations of ~32 cycles each, twelve times: the ~5 us the
+// own-rows part of an event update took; as selects between the table value and the Stirling value (the same values the
+// branches return: bit-identical results) the calls are one straight-line block and the compiler interleaves them.
+__device__ __forceinline__ double lfact_bf(double n, const double2 *tab) {
+    const bool small = n < (double)LFACT_TABLE;
+    const double tv = reinterpret_cast<const double *>(tab + LOGTAB_N)[small ? (n > 0.0 ? (int)n : 0) : 0];
+    const double x = n + 1.0;
+    const double xi = fast_rcp(x), xi2 = xi * xi;
+    const double corr = xi * (8.333333333333333e-2 - xi2 * (2.777777777777778e-3 - xi2 * (7.936507936507937e-4 - xi2 * 5.952380952380952e-4)));
+    const double st = (x - 0.5) * fast_log(x, tab) - x + 0.9189385332046727 + corr;
+    return small ? tv : st;
+}
+__device__ __forceinline__ double lbinom_bf(double n, double k, const double2 *tab) {
+    const double v = lfact_bf(n, tab) - lfact_bf(k, tab) - lfact_bf(n - k, tab);
+    return (k < 0.0 || k > n) ? -INFINITY : v;
+}
+// log(1 - e^-r) by the series alone; `odd` is raised for an argument outside the series' range (the caller redoes those
+// with log1mexp in a cold block)
+__device__ __forceinline__ double log1mexp_series(double r, const double2 *tab, bool &odd) {
+    const double r2 = r * r;
+    odd = odd || !(r >= L1ME_SERIES_MIN && r <= L1ME_SERIES_MAX);
+    return fast_log(r, tab) + r * (-0.5 + r * (4.1666666666666664e-2 - r2 * (3.4722222222222224e-4 - r2 * (5.5114638447971785e-6 - r2 * 1.0333994708994709e-7))));
+}
+
+
 // Out-of-line libm for the once-per-launch scalar work: inlining every exp/log/log1p copy makes
 // the single-workgroup kernels several thousand instructions of straight-line code that is
 // fetched cold on every launch.

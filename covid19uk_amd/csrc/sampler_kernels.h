@@ -1969,20 +1969,27 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
             // only the terms the update changes (terms(new) - terms(old) with the rest cancelled):
             // 4 instead of 6 binomial coefficients, no I->R log
             const double rr0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
+            // (branch-free log-factorials and series: one straight-line block per case, its dozen dependent chains
+            // interleaved by the compiler -- device_math.h: lfact_bf)
             if (mv.tgt == 0) {
                 // S, k_se and E move; the S->E rate (I, F) does not
-                const double L0 = log1mexp(rr0, ltab);
+                bool odd = false;
+                double L0 = log1mexp_series(rr0, ltab, odd);
+                if (odd) L0 = log1mexp(rr0, ltab);
                 const double k1 = kse + dk0;
                 dth += ((k1 != 0.0 ? k1 * L0 : 0.0) - (kse != 0.0 ? kse * L0 : 0.0)) - (double)(dS - dk0) * rr0;
-                dcn += (lbinom(S + dS, k1, ltab) - lbinom(S, kse, ltab)) + (lbinom(E + dE, kei, ltab) - lbinom(E, kei, ltab)) -
+                dcn += (lbinom_bf(S + dS, k1, ltab) - lbinom_bf(S, kse, ltab)) + (lbinom_bf(E + dE, kei, ltab) - lbinom_bf(E, kei, ltab)) -
                        (double)dE * r_ei;
             } else {
                 // E, k_ei and I move, and F with them; S and k_se do not
                 const double rr1 = (ee * ((I + dI) + psiW * (F + dF)) + d.rate_floor) * d.dt;
                 const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
-                dth += (kse != 0.0 ? kse * (log1mexp(rr1, ltab) - log1mexp(rr0, ltab)) : 0.0) - (S - kse) * (rr1 - rr0) -
+                bool odd = false;
+                double L1 = log1mexp_series(rr1, ltab, odd), L0 = log1mexp_series(rr0, ltab, odd);
+                if (odd) { L1 = log1mexp(rr1, ltab); L0 = log1mexp(rr0, ltab); }
+                dth += (kse != 0.0 ? kse * (L1 - L0) : 0.0) - (S - kse) * (rr1 - rr0) -
                        (double)dI * r_ir;
-                dcn += (lbinom(E + dE, kei + dk1, ltab) - lbinom(E, kei, ltab)) + (lbinom(I + dI, kir, ltab) - lbinom(I, kir, ltab)) +
+                dcn += (lbinom_bf(E + dE, kei + dk1, ltab) - lbinom_bf(E, kei, ltab)) + (lbinom_bf(I + dI, kir, ltab) - lbinom_bf(I, kir, ltab)) +
                        (double)dk1 * L_ei - (double)(dE - dk1) * r_ei;
             }
         }
