@@ -270,10 +270,10 @@ def main():
         sampler.sample_bursts(n_bursts, burst, lambda tr_, i: touched.append(int(tr_.events[-1, 0, 0, 0, 0])))
         overlapped = time.perf_counter() - t2
 
-    # dominant kernel of the sweep: the gradient evaluation, 17 per sweep.  15 of them are the inner leapfrog steps -- ONE
-    # persistent launch (k_leap) where it fits the chip, else one k_se_chunk launch per step -- timed in place: HIP events
-    # around that section of ordinary sweeps, on the stream the kernels run on.  The other two are plain k_se launches
-    # (first and last gradient of a trajectory), timed stand-alone.
+    # dominant kernel of the sweep: the gradient evaluation, 17 per sweep.  Where it fits the chip ONE persistent launch
+    # (k_leap) performs all 17 (the whole trajectory but its last half kick); otherwise the 15 inner leapfrog steps are one
+    # k_se_chunk launch each and the end points plain k_se launches.  Timed in place: HIP events around that section of
+    # ordinary sweeps, on the stream the kernels run on; k_se also stand-alone.
     leap_ms, leap_launches, leap_evals = sampler.time_leapfrog(min(200, max(20, K)))
     grad_ms = sampler.time_grad_kernel(200)
     M, T, P = cov.M, cov.T, model.P
@@ -478,12 +478,13 @@ def main():
                        "sweep": "HMC(16 leapfrogs) + 5 x [S->E move, E->I move, S->E occult, E->I occult]",
                        "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] (uint16 counts) + kernel results per sweep",
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"kernel": ("k_leap<TSM,NTC,2> (persistent: the 15 inner leapfrog steps of a trajectory in one launch -- per step the "
-                                    "S->E term + gradient sums of all chains from register-resident cells, then the chunk roles' leapfrog "
-                                    "update; 15 of the sweep's 17 gradient evaluations)") if leap_launches == 1 else
-                                   ("k_se_chunk (one launch per inner leapfrog step: gradient tiles + chunk roles; 15 of the sweep's 17 "
+            "roofline": {"kernel": (f"k_leap<TSM,NTC,2> (persistent: {leap_evals} of the sweep's 17 gradient evaluations in one launch -- the "
+                                    "whole HMC trajectory but its last half kick: per evaluation the S->E term's gradient sums of all chains "
+                                    "from register-resident cells (and its value at the two end points), then the chunk roles' leapfrog update)")
+                                   if leap_launches == 1 else
+                                   (f"k_se_chunk (one launch per inner leapfrog step: gradient tiles + chunk roles; {leap_evals} of the sweep's 17 "
                                     "gradient evaluations)" if leap_launches == leap_evals else
-                                    "k_se + k_hmc_chunk (two launches per inner leapfrog step; 15 of the sweep's 17 gradient evaluations)"),
+                                    f"k_se + k_hmc_chunk (two launches per inner leapfrog step; {leap_evals} of the sweep's 17 gradient evaluations)"),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_uses": "algorithmic bytes of SURVEY.md 8d (fp64 events + vectors per chain, Cstar once) x the gradient "
@@ -496,14 +497,15 @@ def main():
                                  "memory traffic is far below the algorithmic bytes: what bounds it is the fp64 vector issue rate of the "
                                  "tile phase (~70 instructions per cell) and the two in-L2 hand-offs per step -- `frac` prices it "
                                  "against the HBM time of the algorithmic bytes as SURVEY.md 8d defines",
-                         "k_se_stand_alone": {"kernel": "k_se<GRAD=true,SRC=planes> (the other 2 of the 17 evaluations)",
+                         "k_se_stand_alone": {"kernel": "k_se<GRAD=true,SRC=planes> (the streaming form of one evaluation: what the multi-launch "
+                                                        "forms run at a trajectory's end points)",
                                               "mean_launch_us": 1e3 * grad_ms, "achieved": achieved_k_se,
                                               "frac": achieved_k_se / HBM_PEAK_GBPS,
                                               "kernel_bytes_per_launch": kernel_bytes,
                                               "frac_kernel_bytes": kernel_bytes / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                               "frac_traffic": (traffic_k_se / (grad_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_k_se else None,
                                               "traffic": traffic_k_se},
-                         "frac_time_weighted_17": (17 * alg_bytes / ((leap_ms + 2 * grad_ms) * 1e-3) / 1e9) / HBM_PEAK_GBPS},
+                         "frac_time_weighted_17": (17 * alg_bytes / ((leap_ms + max(0, 17 - leap_evals) * grad_ms) * 1e-3) / 1e9) / HBM_PEAK_GBPS},
             "roofline_stateless": stateless,
             "spinup_sweeps": spin_sweeps,
             "steady_state": steady,
