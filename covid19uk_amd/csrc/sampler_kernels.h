@@ -1513,11 +1513,18 @@ constexpr int LEAP_CH = 1024;        // 64-bit words of Chains::leap per chain
 #define LALL(k) do {} while (0)
 #define RPROBE(k) do {} while (0)
 #endif
+// A wait of k_leap.  Every wait is bounded (~1 s), and once ANY wait of the chain has timed out -- its workgroups cannot
+// all have been resident: something else holds part of the chip, e.g. a second process with a launch of the same kind -- the
+// chain's fatal counter is non-zero and every later wait of the chain gives up at its first look at it (every 256 polls), so
+// that a launch that cannot complete drains in about a second instead of a second per step; the host finds the counter at
+// the next read of the trace and fails loudly (check_handoffs).
 __device__ __forceinline__ void leap_wait(const unsigned long long *flag, unsigned long long target, unsigned *late) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) { if ((threadIdx.x & 63) == 0) *late += 1; break; }   // ~0.1 s: never seen; counted, no hang
+        ++spins;
+        if ((spins & 255) == 0 && __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (spins > (1 << 21)) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
 }
 
@@ -1776,7 +1783,9 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
             int spins = 0;                                       // every shard's tiles are in: all of (up to) eight flags show the step
             while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(flag1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stepno) != 0ull) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { if (lane_w == 0) *late += 1; break; }
+                ++spins;
+                if ((spins & 255) == 0 && __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // see leap_wait
+                if (spins > (1 << 21)) { if (lane_w == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         };
         if (wv != 0) {

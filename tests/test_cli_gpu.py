@@ -106,3 +106,28 @@ def test_two_rank_job_equals_one_process_with_all_chains(tmp_path):
     # the chains are different chains
     with hdf5io.File(str(two / "posterior_chain0.hd5"), "r") as fa, hdf5io.File(str(two / "posterior_chain3.hd5"), "r") as fb:
         assert not np.array_equal(fa.read("/samples/psi"), fb.read("/samples/psi"))
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment -- the way the driver calls it -- must start its N
+    ranks itself (a torch.distributed.run child), relay rank 0's JSON line and pass the exit code on.  Rehearsed with two
+    ranks that share this box's one GPU and meet over gloo (BENCH_SHARE_GPU / BENCH_DIST_BACKEND: the collectives of the
+    N > 1 path on CPU tensors; RCCL itself needs the driver's multi-GPU node)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=H.ROOT, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--workload", "ni11", "--chains-per-gpu", "3", "--adapt-sweeps", "5", "--spinup-seconds", "0.05",
+                        "--no-cpu-baseline", "--no-cli", "--no-chains-scaling", "--no-egress"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
+    assert out["config"]["chains_total"] == 6 and out["value"] > 0 and out["all_log_probs_finite"]
+    assert "launching:" in r.stderr
+    # a wrong rank count under an external launcher is refused
+    bad = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                         cwd=str(tmp_path), env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 2
