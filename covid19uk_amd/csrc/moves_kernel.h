@@ -27,6 +27,17 @@ namespace seir {
 #define MSTAMP(i) do {} while (0)
 #endif
 
+// developer probe (tools/dev/pair_timeline.py): plain stores of the clock by thread 0 of chain 0's workgroups, per step of
+// the pair launch: Chains::leap_st[(slot * 12 + step) * 16 + i]
+#ifdef PAIR_STAMPS
+#define QSTAMP(slot_, step_, i_) do { if (threadIdx.x == 0 && (b_stamp) == 0 && (step_) < 12 && (slot_) < 27) \
+    ch.leap_st[((size_t)(slot_) * 12 + (step_)) * 16 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define QWAIT(slot_, step_, i_) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QSTAMP(slot_, step_, i_); } while (0)
+#else
+#define QSTAMP(slot_, step_, i_) do {} while (0)
+#define QWAIT(slot_, step_, i_) do {} while (0)
+#endif
+
 constexpr int MVB = 512;              // threads
 constexpr int MVW = MVB / WAVE;       // waves
 constexpr int MVU = 4;                // cells in flight per thread in the band loops
@@ -849,12 +860,16 @@ __device__ __forceinline__ void wait_token(const unsigned *p_, unsigned token, u
 }
 __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
                                                 const Chains &ch, int b, int bx, int nband, unsigned token, bool has_r1,
-                                                bool has_r2, int buf) {
+                                                bool has_r2, int buf, int st_slot = 0, int st_step = 0) {
+    const int b_stamp = b - d.b0;
+    (void)b_stamp;
     __shared__ Move mvA, mvB, fp;
     __shared__ int mv_sel;
     __shared__ double sh_th[MVW], sh_cn[MVW];
     __shared__ double2 ltab[LDSTAB_N];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                          // (see pair_step)
+    const int wave = tid >> 6, lane = tid & 63;
     if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
     const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];      // constant during the event updates
     const unsigned *done = ch.done + (size_t)b * 2 * TAIL_STRIDE;
@@ -863,6 +878,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     // ---- the update accepted in this launch (token 4, early in the authoritative role): its descriptor, and what its F
     // band needs for this workgroup's rows -- coefficients and the F values themselves (nobody writes F but this code)
     if (tid == 0) wait_token(done + 4, token, ch.late + ch.late_fatal + b);
+    QSTAMP(st_slot, st_step, 1);
     __syncthreads();
     move_copy_l2(&fp, ch.fpend + b, 128);
     __syncthreads();
@@ -892,6 +908,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
         // the speculative role publishes its descriptor (token 3) well before it is done (token 1)
         if (has_r1) wait_token(done + 3, token, ch.late + ch.late_fatal + b);
     }
+    QSTAMP(st_slot, st_step, 2);
     __syncthreads();
     move_copy_l2(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
     __syncthreads();
@@ -952,6 +969,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
         return dth;
     };
     double dth = evaluate(mvA);
+    QSTAMP(st_slot, st_step, 3);
     if (tid == 0) {
         wait_token(done + 0, token, ch.late + ch.late_fatal + b);
         mv_sel = ld_l2(ch.mvsel + (size_t)buf * s.B + b);
@@ -972,11 +990,13 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
         for (int k = 0; k < MVW; ++k) a += sh_th[k];
         out[0] = a;
         out[1] = 0.0;
+        QSTAMP(st_slot, st_step, 4);
         // the F band: once nobody reads F any more
         if (has_fp) {
             if (has_r1) wait_token(done + 1, token, ch.late + ch.late_fatal + b);
             if (has_r2) wait_token(done + 2, token, ch.late + ch.late_fatal + b);
         }
+        QSTAMP(st_slot, st_step, 5);
     }
     if (!has_fp) return;
     __syncthreads();
@@ -1008,10 +1028,13 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     (void)sh_cn;
 }
 
+// One pair of updates by the workgroup in `slot` of chain b: the body of k_move_pair (one launch per pair) and of one
+// step of k_move_pairs (every pair of a sweep in one launch).  nroles: role slots of the grid (the speculative roles in
+// the low slots, role 0 in the last), nband: band workgroups per chain that take part in THIS pair (0: none).
 template <int NCH>
-__global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
-                                                   MoveSpec next, MoveSpec se_next, int have_prev, int have_pre,
-                                                   int pbuf, int nbk, int lidx, int dbg, int nband) {
+__device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s, const Chains &ch,
+                                          MoveSpec se, MoveSpec next, MoveSpec se_next, int have_prev, int have_pre, int pbuf,
+                                          int lidx, int dbg, int nband, int nroles, int slot, int b) {
     extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // rg [M] | rt [M]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
@@ -1019,17 +1042,19 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     __shared__ double pre_down[2], s_down[4];
     __shared__ double2 ltab[LDSTAB_N];
     __shared__ int s_sel, s_acc_se, s_conf, s_late, s_late2, s_use_pre, s_trans;
-    debug_skew(d);
-    // block id = slot * nbk + chain with the speculative roles in the low slots: they are dispatched first,
-    // so an authoritative workgroup never holds a CU waiting for a partner that has not been placed yet,
-    // whatever the number of chains; the closing launch has role 0 only
-    const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;
-    const int b = d.b0 + (int)blockIdx.x - slot * nbk, tid = threadIdx.x;
-    if (d.nlive > 0 && (int)blockIdx.x - slot * nbk >= d.nlive) return;             // a chain of the layout that does not exist
+    // (opaque to the compiler: inside k_move_pairs' loop nothing derived from the thread or the chain is to be computed
+    // once ahead of the loop and kept in registers across every step)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    asm volatile("" : "+s"(b));
+    const int b_stamp = b - d.b0;
+    (void)b_stamp;
+    QSTAMP(slot, lidx, 0);
     if (slot >= nroles) {                                  // band workgroups (the highest block ids)
+        if (nband == 0) return;
         const unsigned tok = ch.sweep[b] * 64u + (unsigned)lidx + 1u;
         const bool r1 = next.kind >= 0 && nroles >= 2, r2 = se_next.kind >= 0 && nroles == 3;
-        pair_band_block(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1);
+        pair_band_block(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1, slot, lidx);
         return;
     }
     const int role = slot == nroles - 1 ? 0 : slot + 1;
@@ -1065,7 +1090,9 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     int pre_se[PRE_RT], pre_nx[PRE_RT];
     mv_prefetch_rows(d, w, s, b, se, do_se && pre_ok, pre_se);
     mv_prefetch_rows(d, w, s, b, mine, (role == 2 || do_nx) && pre_ok, pre_nx);
+    QWAIT(slot, lidx, 4);
     const unsigned token = ch.sweep[b] * 64u + (unsigned)lidx + 1u;       // unique per (sweep, launch): lidx < 63
+    QWAIT(slot, lidx, 5);
     // ... all of it issued before the first wait: the pending descriptors, k_move_delta's partial sums, the
     // own-rows parts, the pre-drawn proposal and its note -- one round trip for the whole entry
     double dth0 = 0.0, dcn0 = 0.0;
@@ -1074,6 +1101,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         move_copy(&pendB, ch.mvfix + (size_t)pbuf * s.B + b, 128);
         if (tid == 192) s_sel = ch.mvsel[(size_t)pbuf * s.B + b];
         if (tid >= 196 && tid < 200) s_down[tid - 196] = ch.Down[(((size_t)pbuf * 2 + ((tid - 196) >> 1)) * s.B + b) * 2 + ((tid - 196) & 1)];
+        QWAIT(slot, lidx, 7);
         for (int i = tid; i < s.nrb_d; i += MVB) {
             dth0 += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
             dcn0 += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
@@ -1097,8 +1125,11 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     psi = w.scal[(size_t)b * NSCAL + SC_PSI];
     if (role != 0) {
         // the totals are in registers: tell role 0 it may start writing
+        QSTAMP(slot, lidx, 6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QSTAMP(slot, lidx, 12);
         __syncthreads();
+        QSTAMP(slot, lidx, 13);
         // test hooks (seir_sampler_desc::debug_pair): 1 = role 1 posts its token late, 2 = never; 4 / 8: role 2
         const int late_bit = role == 1 ? 1 : 4, absent_bit = role == 1 ? 2 : 8;
         if (dbg & late_bit)
@@ -1108,6 +1139,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     }
     if (do_se && !pre_avail) mv_draw(s, ch, b, se, sm_se, T);
     if (role != 0 || do_nx) mv_draw(s, ch, b, mine, sm_nx, T);
+    QSTAMP(slot, lidx, 14);
     MvLds L{};
     int *rtl = dyn_i + M;
     L.rt = rtl;
@@ -1117,6 +1149,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     const Move *pendp = nullptr;
     if (have_prev) {
         __syncthreads();                                   // the descriptors fetched at entry are in LDS
+        QSTAMP(slot, lidx, 15);
         const Move &pend = s_sel ? pendB : pendA;          // speculative one, or re-drawn after a row conflict
         pendp = &pend;
         mv_sum2(dth0, dcn0, sm_nx.dred);
@@ -1133,8 +1166,10 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
 #if defined(SEIR_STAMPS) && defined(SEIR_STAMP_PROPOSE)
         L.stamp_hs = stamp_hs; L.stamp_on = rstamp_on;
 #endif
+        QSTAMP(slot, lidx, 1);
         mv_rows_to_lds(d, w, s, b, mine, pre_ok, pre_nx, fix, L, rtl);
         mv_propose<NCH>(d, w, s, ch, b, mine, sm_nx, L, ltab);
+        QSTAMP(slot, lidx, 2);
         RSTAMP(10);
         Move *out = (role == 1 ? ch.mv : ch.mvs) + (size_t)(pbuf ^ 1) * s.B + b;
         move_copy(out, &sm_nx.mv, MVB - WAVE);             // by the last wave: nobody's loads queue behind the store
@@ -1150,6 +1185,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         double *od = role == 1 ? ch.Down + (((size_t)(pbuf ^ 1) * 2 + 0) * s.B + b) * 2
                                : ch.DownS + ((size_t)(pbuf ^ 1) * s.B + b) * 2;
         mv_own_rows_to_down(d, c, w, b, sm_nx.mv, psi, ltab, fpp, sm_nx.dred, od);
+        QSTAMP(slot, lidx, 3);
         RSTAMP(11);
         if (nband > 0) {                                   // band workgroups: this role reads F no more, its output is in L2
             __syncthreads();
@@ -1221,6 +1257,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         lds_barrier();
     }
     PSTAMP(1);
+    QSTAMP(slot, lidx, 1);
     // ---- (2) the whole S->E-type update
     bool se_acc = false;
     if (do_se) {
@@ -1285,6 +1322,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         if (nband > 0 && tid == 0)
             __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 5, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PSTAMP(5);
+        QSTAMP(slot, lidx, 2);
     }
     // ---- (3) certify role 1's proposal; closing launch: advance the sweep counter
     if (next.kind == -2 && tid == 0) ch.sweep[b] += 1;
@@ -1320,6 +1358,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
                                 ch.Down + (((size_t)(pbuf ^ 1) * 2 + 1) * s.B + b) * 2);
         }
         PSTAMP(7);
+        QSTAMP(slot, lidx, 3);
     }
     // ---- (4) the note for the next launch about the proposal role 2 is pre-drawing
     if (do_pre && tid == 0) {
@@ -1348,6 +1387,96 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
         __syncthreads();
         if (tid == 0)
             __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 0, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, MoveSpec se,
+                                                   MoveSpec next, MoveSpec se_next, int have_prev, int have_pre,
+                                                   int pbuf, int nbk, int lidx, int dbg, int nband) {
+    debug_skew(d);
+    // block id = slot * nbk + chain with the speculative roles in the low slots: they are dispatched first,
+    // so an authoritative workgroup never holds a CU waiting for a partner that has not been placed yet,
+    // whatever the number of chains; the closing launch has role 0 only
+    const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;
+    const int b = d.b0 + (int)blockIdx.x - slot * nbk;
+    if (d.nlive > 0 && (int)blockIdx.x - slot * nbk >= d.nlive) return;             // a chain of the layout that does not exist
+    pair_step<NCH>(d, c, w, s, ch, se, next, se_next, have_prev, have_pre, pbuf, lidx, dbg, nband, nroles, slot, b);
+    const int b_stamp = b - d.b0;
+    (void)b_stamp;
+    QSTAMP(slot, lidx, 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_move_pairs: EVERY pair of a sweep, and the closing step, in ONE launch -- the grid of k_move_pair with band
+// workgroups (3 roles + nband band workgroups per chain, every workgroup resident, a chain's workgroups on one XCD),
+// each workgroup walking through the steps k_move_pair is launched for.  What a launch boundary gave is restated per
+// chain: a workgroup that has finished step i drains its stores (they are acknowledged by the XCD's L2), counts in on
+// the chain's counter (Chains::pbar) and waits for the last one to raise the flag; then it drops its CU's L1 and scalar
+// cache, so that the plain loads of step i + 1 see what any workgroup of the chain wrote in step i, exactly as the
+// loads of a new launch would.  Inside a step nothing changes: the hand-offs of k_move_pair (tokens unique per sweep
+// and step, reads past the L1 of everything written in the same step).  What it saves is what a launch costs a
+// latency chain like this one: the dispatch ramp, the kernel-argument and first-touch misses, a cold instruction
+// cache for a path of a few thousand instructions executed once, and the drain at the end.
+// Chains are independent: there is no barrier across chains.
+// ---------------------------------------------------------------------------------------------
+constexpr int PBAR_STRIDE = 64;                               // 32-bit words per chain: counter at 0, flag at 32
+__device__ __forceinline__ void pair_chain_barrier(const Chains &ch, int b, unsigned nwg, unsigned token, int b_stamp = 0,
+                                                   int st_slot = 0, int st_step = 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores of the step are in L2
+    __syncthreads();
+    QSTAMP(st_slot, st_step, 10);
+    if (threadIdx.x == 0) {
+        unsigned *cnt = ch.pbar + (size_t)b * PBAR_STRIDE, *flag = cnt + 32;
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == nwg) {
+            // the last one: nobody counts in again before it has seen the flag, so the counter can be cleared first
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            wait_token(flag, token, ch.late + ch.late_fatal + b);
+        }
+        // Drop this CU's L1, so that plain loads of the next step see what other workgroups wrote in this one.  ONE wave
+        // per workgroup: an agent-scope invalidate (buffer_inv sc1) is also a request to the XCD's L2, where the requests of
+        // a whole grid queue up -- with every wave issuing one (8 x 27 x 8 of them per step) the next step's first loads
+        // came back 10 us late (tools/dev/pair_timeline.py); the narrower `buffer_inv sc0` leaves the L1 as it is
+        // (tools/probes/l1inv_probe.hip).  The instruction completes like a load: waited for before the barrier below
+        // lets the other waves go.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_dcache_inv();                      // (and the scalar cache, should a uniform load have gone through it)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    QSTAMP(st_slot, st_step, 11);
+    __syncthreads();
+}
+
+template <int NCH>
+__global__ __launch_bounds__(MVB) void k_move_pairs(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int npairs, int pre_on,
+                                                    int nbk, int dbg, int nband) {
+    debug_skew(d);
+    const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;   // 3 roles
+    const int b = d.b0 + (int)blockIdx.x - slot * nbk;
+    if (d.nlive > 0 && (int)blockIdx.x - slot * nbk >= d.nlive) return;             // a chain of the layout that does not exist
+    const unsigned tok0 = ch.sweep[b] * 64u;                  // (the closing step advances the counter when it is done)
+    const MoveSpec none{-1, 0, 0, 0};
+    for (int pair = 0; pair <= npairs; ++pair) {
+        // as enqueue_sweep launches k_move_pair: scan = pair / 2, the first half of a scan is the event-time moves, the second
+        // the occults; step npairs is the closing one: role 0 finalizes the last E->I-type proposal and advances the sweep counter
+        const bool closing = pair == npairs;
+        const int scan = pair >> 1, half = pair & 1, nh = half ^ 1, nscan = scan + half;
+        const bool pre = pre_on && pair + 1 < npairs;
+        const MoveSpec se = closing ? none : MoveSpec{half, 0, 2 * half, scan};
+        const MoveSpec nx = closing ? MoveSpec{-2, 0, 0, 0} : MoveSpec{half, 1, 2 * half + 1, scan};
+        const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : none;
+        pair_step<NCH>(d, c, w, s, ch, se, nx, se_next, pair > 0 ? 1 : 0, (pair > 0 && pre_on && !closing) ? 1 : 0, pair & 1,
+                       closing ? 62 : pair, closing ? 0 : dbg, closing ? 0 : nband, nroles, slot, b);
+        if (closing) break;
+        const int b_stamp = b - d.b0;
+        (void)b_stamp;
+        QSTAMP(slot, pair, 8);
+        pair_chain_barrier(ch, b, (unsigned)(nroles + nband), tok0 + (unsigned)pair + 1u, b_stamp, slot, pair);
+        QSTAMP(slot, pair, 9);
     }
 }
 

@@ -91,6 +91,9 @@ struct Chains {
                                                          // from (band tokens, k_se_chunk's tile flag): the workgroup went on without its data
     int late_fatal;
                                                          //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
+    unsigned *pbar;                                      // [B][PBAR_STRIDE] k_move_pairs: the chain's workgroups that have finished the
+                                                         //     current step (counter, cleared by the last one) and, a line further, the
+                                                         //     token of the last step all of them have finished
     unsigned *done;                                      // [B][2 TAIL_STRIDE] k_move_pair with band workgroups: token of the launch whose
                                                          //     role r has finished, at [b][r] (a chain's three tokens in its own line)
     unsigned long long *tail;                            // [B][TAIL_STRIDE] k_se_chunk: tiles of the chain that have arrived, over

@@ -971,8 +971,9 @@ struct seir_sampler {
     bool xcd_local = false;       // blocks with the same id mod 8 share an XCD (k_xcc_probe at creation)
     unsigned long long tail_count = 0;   // tiles per chain counted in by all k_se_chunk launches so far (Chains::tail)
     int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
-    int moves_mode = 0;           // 0 = paired launches (k_move_pair) with the S->E-type proposal pre-drawn one launch ahead (3: the same,
-                                  //     never with band workgroups in the pair launch);
+    int moves_mode = 0;           // 0 = paired updates (k_move_pair) with the S->E-type proposal pre-drawn one pair ahead -- every pair of a
+                                  //     sweep in one launch (k_move_pairs) where band workgroups can be part of it, else one launch per
+                                  //     pair (4: always one launch per pair; 3: the same, never with band workgroups in the pair launch);
                                   // 1 = one proposal kernel per update (k_move_pa2); 2 = paired launches without the pre-draw
     int graph_skew = 0, graph_aff = 3;   // context options the captured graph was built with
     bool have_state = false;
@@ -1033,8 +1034,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
     if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
-    if (ds->moves_mode < 0 || ds->moves_mode > 3 || ds->hmc_mode < 0 || ds->hmc_mode > 4)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..3, hmc_mode 0..4");
+    if (ds->moves_mode < 0 || ds->moves_mode > 4 || ds->hmc_mode < 0 || ds->hmc_mode > 4)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..4");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
@@ -1107,6 +1108,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.irl0, (size_t)B);
     S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
     S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
+    S_ALLOC(ch.pbar, (size_t)B * PBAR_STRIDE);
     S_ALLOC(ch.hand2, (size_t)B);
     S_ALLOC(ch.mvs, (size_t)2 * B);
     S_ALLOC(ch.DownS, (size_t)2 * B * 2);
@@ -1143,7 +1145,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
         }
         if (e != hipSuccess) rc = fail(SEIR_ERR_DEVICE, "sampler stream setup failed: %s", hipGetErrorString(e));
     }
-    if (!rc && (s->hmc_tail || s->moves_mode == 0 || s->moves_mode == 2)) {
+    if (!rc && (s->hmc_tail || s->moves_mode == 0 || s->moves_mode == 2 || s->moves_mode == 4)) {
         // Do blocks with the same id mod 8 share an XCD here?  (probe_xcd_local)
         if (ctx->xcd_local < 0) ctx->xcd_local = probe_xcd_local(ctx->stream) ? 1 : 0;
         const bool ok = ctx->xcd_local == 1;
@@ -1543,7 +1545,9 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const int nch = d.Tp <= 6 * WAVE ? 6 : d.Tp <= 12 * WAVE ? 12 : 16;
         auto pair_fn = nch == 6 ? k_move_pair<6> : nch == 12 ? k_move_pair<12> : k_move_pair<16>;
         auto pa2_fn = nch == 6 ? k_move_pa2<6> : nch == 12 ? k_move_pa2<12> : k_move_pa2<16>;
+        auto pairs_fn = nch == 6 ? k_move_pairs<6> : nch == 12 ? k_move_pairs<12> : k_move_pairs<16>;
         if (plds > 64 * 1024 && !s->move_lds_attr) {
+            (void)hipFuncSetAttribute((const void *)pairs_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             (void)hipFuncSetAttribute((const void *)pair_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             (void)hipFuncSetAttribute((const void *)pa2_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             s->move_lds_attr = true;
@@ -1569,12 +1573,22 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             const int nband = band_in_pair ? nband_fit : 0;
             SamplerCfg cp = c;
             if (band_in_pair) cp.nrb_d = nband;                          // the band's partial sums: one pair per band workgroup
-            for (int scan = 0; scan < c.n_scans; ++scan)
+            // every pair of the sweep and the closing step in ONE launch (k_move_pairs): the grid of a pair launch with band
+            // workgroups, resident for the whole sweep -- under the same conditions
+            const bool persistent = band_in_pair && s->moves_mode == 0 && npairs > 0;
+            if (persistent) {
+                hipLaunchKernelGGL(pairs_fn, dim3((3 + nband) * nbk), dim3(MVB), plds, st, dp, ctx->c, ctx->w, cp, s->ch, npairs, 1, nbk,
+                                   s->pair_debug, nband);
+                if (s->record_events) fpend_in_record = 1;
+                else hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
+                advanced = 1;
+            }
+            for (int scan = 0; scan < (persistent ? 0 : c.n_scans); ++scan)
                 for (int half = 0; half < 2; ++half) {
                     const int pair = 2 * scan + half;
                     const MoveSpec se{half, 0, 2 * half, scan}, nx{half, 1, 2 * half + 1, scan};
                     // a third role pre-draws the S->E-type proposal of the next pair (same sweep)
-                    const bool pre = (s->moves_mode == 0 || s->moves_mode == 3) && pair + 1 < npairs;
+                    const bool pre = (s->moves_mode == 0 || s->moves_mode == 3 || s->moves_mode == 4) && pair + 1 < npairs;
                     const int nh = (half + 1) & 1, nscan = scan + (half == 1 ? 1 : 0);
                     const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : MoveSpec{-1, 0, 0, 0};
                     hipLaunchKernelGGL(pair_fn, dim3(((pre ? 3 : 2) + nband) * nbk), dim3(MVB), plds, st, dp, ctx->c, ctx->w, cp, s->ch,
@@ -1585,7 +1599,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                         hipLaunchKernelGGL((k_move_delta<false>), gm, dim3(DELTA_THREADS), 0, st, d, ctx->c, ctx->w, c, s->ch, pbuf, 1);
                     have_prev = 1;
                 }
-            if (have_prev) {
+            if (have_prev && !persistent) {
                 const MoveSpec none{-1, 0, 0, 0}, close{-2, 0, 0, 0};
                 hipLaunchKernelGGL(pair_fn, dim3(nb), dim3(MVB), plds, st, d, ctx->c, ctx->w, cp, s->ch, none, close, none, 1,
                                    0, pbuf, nb, 62, 0, 0);
@@ -1825,7 +1839,7 @@ extern "C" int seir_debug_read_ts(seir_ctx *ctx, double *out, int64_t n) {
 }
 #endif
 
-#ifdef LEAP_STAMPS
+#if defined(LEAP_STAMPS) || defined(PAIR_STAMPS)
 // [B][16][8] stamps of k_leap; reset = 1: min-words to ~0, max-words to 0 (call before the sweep to look at)
 extern "C" int seir_debug_leap_stamps(seir_sampler *s, unsigned long long *out, int reset) {
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));

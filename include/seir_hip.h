@@ -189,14 +189,18 @@ typedef struct {
                                        buffer and half the bytes over PCIe; a count > 65535 makes the read fail) */
     uint64_t seed;
     /* ---- ABI v2: launch form and test hooks; all-zero = the defaults ---------------------------- */
-    int32_t moves_mode;             /* 0: paired event-update launches (k_move_pair) with the S->E-type proposal
-                                       pre-drawn one launch ahead; 1: one proposal kernel per update (k_move_pa2)
-                                       -- kept as a cross-check; 2: paired launches without the pre-draw; 3: as 0 with
-                                       the band part of the E->I-type log-ratio always as its own launch
-                                       (k_move_delta).  0 and 2 let workgroups of the pair launch evaluate it where
-                                       all of a chain's workgroups share an XCD (seir_sampler_xcd_local; any number of chains in the
-                                       layout of the next multiple of 8, while every workgroup of the launch fits the chip).
-                                       Same draws in all four */
+    int32_t moves_mode;             /* 0: paired event updates (k_move_pair's steps) with the S->E-type proposal
+                                       pre-drawn one pair ahead -- every pair of a sweep and the closing step in ONE
+                                       launch (k_move_pairs: the pair launch's grid with band workgroups, resident for
+                                       the sweep; between two steps a chain's workgroups meet at a counter and drop
+                                       their L1) where all of a chain's workgroups share an XCD
+                                       (seir_sampler_xcd_local; any number of chains in the layout of the next multiple
+                                       of 8, while every workgroup of the launch fits the chip), else one launch per
+                                       pair; 4: always one launch per pair (k_move_pair, band workgroups in the launch
+                                       under the same condition); 1: one proposal kernel per update (k_move_pa2) --
+                                       kept as a cross-check; 2: as 4 without the pre-draw; 3: as 4 with the band part
+                                       of the E->I-type log-ratio always as its own launch (k_move_delta).
+                                       Same draws in all five */
     int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks; all L-1 of them in ONE persistent launch
                                        (k_leap: the gradient tiles keep their cells in registers over the steps, tiles and
                                        chunk roles hand each other the partial sums / the next tables through the XCD's L2)

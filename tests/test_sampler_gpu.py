@@ -720,11 +720,11 @@ def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, B,
     u = synth.jitter_params(case["u"], B, scale=0.01 if name == "ni11" else 0.002, seed=5, T=case["k"].T)
     ev = np.stack([case["events"]] * B)
     out = {}
-    for mode, skew, dbg in (("paired-delta", 0, 0), ("paired", 0, 0), ("paired", 1, 0), ("paired", 0, 5)):
+    for mode, skew, dbg in (("paired-delta", 0, 0), ("paired", 0, 0), ("paired", 1, 0), ("paired", 0, 5), ("paired-launch", 0, 0)):
         with api[0](case["cov"], case["init"], max_chains=B) as model:
             model.set_option(debug_skew=skew)
             with api[1](model, cfg, B, seed=91, trace_capacity=n, moves=mode, debug_pair=dbg) as s:
-                if mode == "paired" and not s.xcd_local():
+                if mode != "paired-delta" and not s.xcd_local():
                     pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the fused form is not used")
                 s.set_state(u, ev)
                 s.set_kernel(step_size=eps)
@@ -735,7 +735,7 @@ def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, B,
                 out[(mode, skew, dbg)] = (tr, s.get_state())
     ref, ref_state = out[("paired-delta", 0, 0)]
     base, base_state = out[("paired", 0, 0)]
-    for key in (("paired", 0, 0), ("paired", 1, 0), ("paired", 0, 5)):
+    for key in (("paired", 0, 0), ("paired", 1, 0), ("paired", 0, 5), ("paired-launch", 0, 0)):
         got, got_state = out[key]
         assert np.array_equal(ref.events, got.events), key
         np.testing.assert_allclose(got.theta, ref.theta, rtol=1e-12, atol=0.0, err_msg=str(key))
