@@ -858,6 +858,12 @@ __device__ __forceinline__ void wait_token(const unsigned *p_, unsigned token, u
         if (++spins > (1 << 22)) { *late += 1; break; }       // ~0.1 s: never seen; counted, no hang
     }
 }
+// SOLO (k_move_pairs): the workgroup has its CU to itself and its L1 was emptied when the step began, so what it loads of
+// the planes AFTER the token that declares them final cannot be an older copy: plain loads, which a wave issues back to
+// back, where the launch-per-pair form (other workgroups of the chain may share the CU and its L1) reads past the L1
+template <bool SOLO, typename TT>
+__device__ __forceinline__ TT ld_band(const TT *p_) { return SOLO ? *p_ : ld_l2(p_); }
+template <bool SOLO>
 __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
                                                 const Chains &ch, int b, int bx, int nband, unsigned token, bool has_r1,
                                                 bool has_r2, int buf, int st_slot = 0, int st_step = 0) {
@@ -895,7 +901,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
             const int t = fp.LO + q * WAVE + lane;
-            Fpre[r][q] = (onr && t <= fp.HI) ? ld_l2(w.F + ((size_t)b * d.Mp + j) * d.Tp + t) : 0.0;
+            Fpre[r][q] = (onr && t <= fp.HI) ? ld_band<SOLO>(w.F + ((size_t)b * d.Mp + j) * d.Tp + t) : 0.0;
         }
     }
     const bool pre_ok = !has_fp || fp.HI - fp.LO < NPF * WAVE;      // a longer hull (dmax > 127): the loop at the end reloads
@@ -949,8 +955,8 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
                         if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF[r] += coef[r][i];
                     act[r] = on[r] && t <= mv.HI && dF[r] != 0.0;
                     const size_t q = ((size_t)b * d.Mp + (on[r] ? jr[r] : r_lo)) * d.Tp + (act[r] ? t : mv.LO);
-                    S[r] = (double)ld_l2(w.St[0] + q); I[r] = (double)ld_l2(w.St[2] + q);
-                    kse[r] = (double)ld_l2(w.K[0] + q); F[r] = ld_l2(w.F + q);
+                    S[r] = (double)ld_band<SOLO>(w.St[0] + q); I[r] = (double)ld_band<SOLO>(w.St[2] + q);
+                    kse[r] = (double)ld_band<SOLO>(w.K[0] + q); F[r] = ld_band<SOLO>(w.F + q);
                 }
     #pragma unroll
                 for (int r = 0; r < NR; ++r) {
@@ -1021,7 +1027,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)
                     if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfb[r][i];
-                if (dFp != 0.0) Fr[t] = ld_l2(Fr + t) + dFp;
+                if (dFp != 0.0) Fr[t] = ld_band<SOLO>(Fr + t) + dFp;
             }
         }
     }
@@ -1031,7 +1037,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
 // One pair of updates by the workgroup in `slot` of chain b: the body of k_move_pair (one launch per pair) and of one
 // step of k_move_pairs (every pair of a sweep in one launch).  nroles: role slots of the grid (the speculative roles in
 // the low slots, role 0 in the last), nband: band workgroups per chain that take part in THIS pair (0: none).
-template <int NCH>
+template <int NCH, bool SOLO>
 __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s, const Chains &ch,
                                           MoveSpec se, MoveSpec next, MoveSpec se_next, int have_prev, int have_pre, int pbuf,
                                           int lidx, int dbg, int nband, int nroles, int slot, int b) {
@@ -1039,7 +1045,7 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
     __shared__ PairNote note;
-    __shared__ double pre_down[2], s_down[4];
+    __shared__ double pre_down[2], s_down[4], s_dsum[2];
     __shared__ double2 ltab[LDSTAB_N];
     __shared__ int s_sel, s_acc_se, s_conf, s_late, s_late2, s_use_pre, s_trans;
     // (opaque to the compiler: inside k_move_pairs' loop nothing derived from the thread or the chain is to be computed
@@ -1054,7 +1060,7 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
         if (nband == 0) return;
         const unsigned tok = ch.sweep[b] * 64u + (unsigned)lidx + 1u;
         const bool r1 = next.kind >= 0 && nroles >= 2, r2 = se_next.kind >= 0 && nroles == 3;
-        pair_band_block(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1, slot, lidx);
+        pair_band_block<SOLO>(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1, slot, lidx);
         return;
     }
     const int role = slot == nroles - 1 ? 0 : slot + 1;
@@ -1090,42 +1096,67 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
     int pre_se[PRE_RT], pre_nx[PRE_RT];
     mv_prefetch_rows(d, w, s, b, se, do_se && pre_ok, pre_se);
     mv_prefetch_rows(d, w, s, b, mine, (role == 2 || do_nx) && pre_ok, pre_nx);
-    QWAIT(slot, lidx, 4);
     const unsigned token = ch.sweep[b] * 64u + (unsigned)lidx + 1u;       // unique per (sweep, launch): lidx < 63
-    QWAIT(slot, lidx, 5);
     // ... all of it issued before the first wait: the pending descriptors, k_move_delta's partial sums, the
-    // own-rows parts, the pre-drawn proposal and its note -- one round trip for the whole entry
+    // own-rows parts, the pre-drawn proposal and its note -- one round trip for the whole entry, into registers (a thread
+    // holds at most one word of the descriptors and one of the doubles): the uniforms of this step's proposals (Philox and
+    // a logarithm by a few lanes, ~1 us) are drawn while the loads are in flight, and only then do the values go to LDS
     double dth0 = 0.0, dcn0 = 0.0;
+    int ld_i = 0;
+    double ld_d = 0.0;
     if (have_prev) {
-        move_copy(&pendA, ch.mv + (size_t)pbuf * s.B + b, 64);
-        move_copy(&pendB, ch.mvfix + (size_t)pbuf * s.B + b, 128);
-        if (tid == 192) s_sel = ch.mvsel[(size_t)pbuf * s.B + b];
-        if (tid >= 196 && tid < 200) s_down[tid - 196] = ch.Down[(((size_t)pbuf * 2 + ((tid - 196) >> 1)) * s.B + b) * 2 + ((tid - 196) & 1)];
-        QWAIT(slot, lidx, 7);
-        for (int i = tid; i < s.nrb_d; i += MVB) {
+        if (tid >= 64 && tid < 64 + MOVE_DW) ld_i = reinterpret_cast<const int *>(ch.mv + (size_t)pbuf * s.B + b)[tid - 64];
+        if (tid >= 128 && tid < 128 + MOVE_DW) ld_i = reinterpret_cast<const int *>(ch.mvfix + (size_t)pbuf * s.B + b)[tid - 128];
+        if (tid == 192) ld_i = ch.mvsel[(size_t)pbuf * s.B + b];
+        if (tid >= 196 && tid < 200) ld_d = ch.Down[(((size_t)pbuf * 2 + ((tid - 196) >> 1)) * s.B + b) * 2 + ((tid - 196) & 1)];
+        if (tid < s.nrb_d) {
+            dth0 = ch.Dpart[((size_t)b * s.nrb_d + tid) * 2];
+            dcn0 = ch.Dpart[((size_t)b * s.nrb_d + tid) * 2 + 1];
+        }
+        for (int i = tid + MVB; i < s.nrb_d; i += MVB) {
             dth0 += ch.Dpart[((size_t)b * s.nrb_d + i) * 2];
             dcn0 += ch.Dpart[((size_t)b * s.nrb_d + i) * 2 + 1];
         }
     }
     const bool pre_avail = do_se && have_pre;
     if (pre_avail) {
-        move_copy(&sm_se.mv, ch.mvs + (size_t)pbuf * s.B + b, 256);
-        if (tid >= 320 && tid < 320 + 2 + MMAX)
-            reinterpret_cast<int *>(&note)[tid - 320] = reinterpret_cast<const int *>(ch.prev + (size_t)pbuf * s.B + b)[tid - 320];
-        if (tid == 328 || tid == 329) pre_down[tid - 328] = ch.DownS[((size_t)pbuf * s.B + b) * 2 + (tid - 328)];
+        if (tid >= 256 && tid < 256 + MOVE_DW) ld_i = reinterpret_cast<const int *>(ch.mvs + (size_t)pbuf * s.B + b)[tid - 256];
+        if (tid >= 320 && tid < 320 + 2 + MMAX) ld_i = reinterpret_cast<const int *>(ch.prev + (size_t)pbuf * s.B + b)[tid - 320];
+        if (tid == 328 || tid == 329) ld_d = ch.DownS[((size_t)pbuf * s.B + b) * 2 + (tid - 328)];
     }
+    static_assert(MOVE_DW <= 64 && 2 + MMAX <= 8, "the entry loads of pair_step: disjoint thread ranges");
     double hs_th = 0.0, hs_cn = 0.0, psi = 0.0;
     unsigned tr_slot = 0xffffffffu;
-    if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
+    double2 ld_t = make_double2(0.0, 0.0);
+    if (tid < LDSTAB_N) ld_t = c.logtab[tid];
     if (role == 0 && tid == 0) {
         const double *hs = ch.hs + (size_t)b * NHS;
         hs_th = hs[HS_LP_THETA]; hs_cn = hs[HS_LP_CONST];
         tr_slot = ch.sweep[b] - ch.slot0[0];
     }
     psi = w.scal[(size_t)b * NSCAL + SC_PSI];
+    QSTAMP(slot, lidx, 6);
+    if (do_se && !pre_avail) mv_draw(s, ch, b, se, sm_se, T);
+    if (role != 0 || do_nx) mv_draw(s, ch, b, mine, sm_nx, T);
+    QSTAMP(slot, lidx, 14);
+    if (have_prev) {
+        if (tid >= 64 && tid < 64 + MOVE_DW) reinterpret_cast<int *>(&pendA)[tid - 64] = ld_i;
+        if (tid >= 128 && tid < 128 + MOVE_DW) reinterpret_cast<int *>(&pendB)[tid - 128] = ld_i;
+        if (tid == 192) s_sel = ld_i;
+        if (tid >= 196 && tid < 200) s_down[tid - 196] = ld_d;
+    }
+    if (pre_avail) {
+        if (tid >= 256 && tid < 256 + MOVE_DW) reinterpret_cast<int *>(&sm_se.mv)[tid - 256] = ld_i;
+        if (tid >= 320 && tid < 320 + 2 + MMAX) reinterpret_cast<int *>(&note)[tid - 320] = ld_i;
+        if (tid == 328 || tid == 329) pre_down[tid - 328] = ld_d;
+    }
+    if (tid < LDSTAB_N) ltab[tid] = ld_t;
+    if (have_prev && s.nrb_d <= WAVE && tid < WAVE) {
+        const double a = wave_sum(dth0), a2 = wave_sum(dcn0);
+        if (tid == 0) { s_dsum[0] = 0.0 + a; s_dsum[1] = 0.0 + a2; }
+    }
     if (role != 0) {
         // the totals are in registers: tell role 0 it may start writing
-        QSTAMP(slot, lidx, 6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         QSTAMP(slot, lidx, 12);
         __syncthreads();
@@ -1135,11 +1166,8 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
         if (dbg & late_bit)
             for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(127);   // ~0.35 ms: well inside role 0's bounded wait
         if (tid == 0 && !(dbg & absent_bit))
-            __hip_atomic_store((role == 1 ? ch.hand : ch.hand2) + b, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((role == 1 ? ch.hand : ch.hand2) + b, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (loads done: above)
     }
-    if (do_se && !pre_avail) mv_draw(s, ch, b, se, sm_se, T);
-    if (role != 0 || do_nx) mv_draw(s, ch, b, mine, sm_nx, T);
-    QSTAMP(slot, lidx, 14);
     MvLds L{};
     int *rtl = dyn_i + M;
     L.rt = rtl;
@@ -1152,7 +1180,13 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
         QSTAMP(slot, lidx, 15);
         const Move &pend = s_sel ? pendB : pendA;          // speculative one, or re-drawn after a row conflict
         pendp = &pend;
-        mv_sum2(dth0, dcn0, sm_nx.dred);
+        if (s.nrb_d <= WAVE) {
+            // the partial sums are all in wave 0: its sums went to LDS ahead of the barrier above (the value mv_sum2 gives:
+            // the other waves' parts are zeros)
+            dth0 = s_dsum[0]; dcn0 = s_dsum[1];
+        } else {
+            mv_sum2(dth0, dcn0, sm_nx.dred);
+        }
         dth0 += s_down[s_sel ? 2 : 0];                     // the updated rows' part
         dcn0 += s_down[s_sel ? 3 : 1];
         const double ratio = dth0 + dcn0 + pend.logq;
@@ -1401,7 +1435,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
     const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;
     const int b = d.b0 + (int)blockIdx.x - slot * nbk;
     if (d.nlive > 0 && (int)blockIdx.x - slot * nbk >= d.nlive) return;             // a chain of the layout that does not exist
-    pair_step<NCH>(d, c, w, s, ch, se, next, se_next, have_prev, have_pre, pbuf, lidx, dbg, nband, nroles, slot, b);
+    pair_step<NCH, false>(d, c, w, s, ch, se, next, se_next, have_prev, have_pre, pbuf, lidx, dbg, nband, nroles, slot, b);
     const int b_stamp = b - d.b0;
     (void)b_stamp;
     QSTAMP(slot, lidx, 8);
@@ -1412,7 +1446,7 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
 // workgroups (3 roles + nband band workgroups per chain, every workgroup resident, a chain's workgroups on one XCD),
 // each workgroup walking through the steps k_move_pair is launched for.  What a launch boundary gave is restated per
 // chain: a workgroup that has finished step i drains its stores (they are acknowledged by the XCD's L2), counts in on
-// the chain's counter (Chains::pbar) and waits for the last one to raise the flag; then it drops its CU's L1 and scalar
+// the chain's counter (Chains::pbar) and waits until it shows them all; then it drops its CU's L1 and scalar
 // cache, so that the plain loads of step i + 1 see what any workgroup of the chain wrote in step i, exactly as the
 // loads of a new launch would.  Inside a step nothing changes: the hand-offs of k_move_pair (tokens unique per sweep
 // and step, reads past the L1 of everything written in the same step).  What it saves is what a launch costs a
@@ -1420,32 +1454,36 @@ __global__ __launch_bounds__(MVB) void k_move_pair(Dims d, Consts c, Work w, Sam
 // cache for a path of a few thousand instructions executed once, and the drain at the end.
 // Chains are independent: there is no barrier across chains.
 // ---------------------------------------------------------------------------------------------
-constexpr int PBAR_STRIDE = 64;                               // 32-bit words per chain: counter at 0, flag at 32
-__device__ __forceinline__ void pair_chain_barrier(const Chains &ch, int b, unsigned nwg, unsigned token, int b_stamp = 0,
-                                                   int st_slot = 0, int st_step = 0) {
+constexpr int PBAR_STRIDE = 32;                               // 32-bit words per chain: the counter in a line of its own
+// `target`: what the chain's counter shows once every workgroup of the chain has finished the step -- the counter runs on
+// over the launches (the host knows how many steps have been counted: seir_sampler::pbar_count), so the last one in
+// has nothing to reset or to raise, and the others poll the counter itself
+__device__ __forceinline__ void pair_chain_barrier(const Chains &ch, int b, unsigned target, int b_stamp = 0, int st_slot = 0,
+                                                   int st_step = 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores of the step are in L2
     __syncthreads();
     QSTAMP(st_slot, st_step, 10);
     if (threadIdx.x == 0) {
-        unsigned *cnt = ch.pbar + (size_t)b * PBAR_STRIDE, *flag = cnt + 32;
+        unsigned *cnt = ch.pbar + (size_t)b * PBAR_STRIDE;
         const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == nwg) {
-            // the last one: nobody counts in again before it has seen the flag, so the counter can be cleared first
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            wait_token(flag, token, ch.late + ch.late_fatal + b);
-        }
-        // Drop this CU's L1, so that plain loads of the next step see what other workgroups wrote in this one.  ONE wave
-        // per workgroup: an agent-scope invalidate (buffer_inv sc1) is also a request to the XCD's L2, where the requests of
-        // a whole grid queue up -- with every wave issuing one (8 x 27 x 8 of them per step) the next step's first loads
-        // came back 10 us late (tools/dev/pair_timeline.py); the narrower `buffer_inv sc0` leaves the L1 as it is
+        // Drop this CU's L1, so that plain loads of the next step see what other workgroups wrote in this one -- at once,
+        // not when the count is complete: the launch holds ONE workgroup per CU (its LDS request, k_move_pairs_lds_bytes),
+        // and from here to the end of the wait this one loads nothing but the counter, past the L1, so the cache stays empty.
+        // ONE wave per workgroup, and not all at the same moment: an agent-scope invalidate (buffer_inv sc1) is also a
+        // request to the XCD's L2, where the requests of a whole grid queue up -- with every wave issuing one after the wait
+        // (8 x 27 x 8 of them per step) the next step's first loads came back 10 us late, with one per workgroup after the
+        // wait 1.3 us (tools/dev/pair_timeline.py); the narrower `buffer_inv sc0` leaves the L1 as it is
         // (tools/probes/l1inv_probe.hip).  The instruction completes like a load: waited for before the barrier below
-        // lets the other waves go.
+        // lets the other waves go.  (The scalar cache needs nothing: what is read through it is kernel arguments.)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __builtin_amdgcn_s_dcache_inv();                      // (and the scalar cache, should a uniform load have gone through it)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (old + 1u != target) {
+            int spins = 0;
+            while ((int)(ld_l2(cnt) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { ch.late[ch.late_fatal + b] += 1; break; }     // ~0.1 s: counted, no hang
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     QSTAMP(st_slot, st_step, 11);
     __syncthreads();
@@ -1453,12 +1491,11 @@ __device__ __forceinline__ void pair_chain_barrier(const Chains &ch, int b, unsi
 
 template <int NCH>
 __global__ __launch_bounds__(MVB) void k_move_pairs(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int npairs, int pre_on,
-                                                    int nbk, int dbg, int nband) {
+                                                    int nbk, int dbg, int nband, unsigned pbase) {
     debug_skew(d);
     const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;   // 3 roles
     const int b = d.b0 + (int)blockIdx.x - slot * nbk;
     if (d.nlive > 0 && (int)blockIdx.x - slot * nbk >= d.nlive) return;             // a chain of the layout that does not exist
-    const unsigned tok0 = ch.sweep[b] * 64u;                  // (the closing step advances the counter when it is done)
     const MoveSpec none{-1, 0, 0, 0};
     for (int pair = 0; pair <= npairs; ++pair) {
         // as enqueue_sweep launches k_move_pair: scan = pair / 2, the first half of a scan is the event-time moves, the second
@@ -1469,19 +1506,24 @@ __global__ __launch_bounds__(MVB) void k_move_pairs(Dims d, Consts c, Work w, Sa
         const MoveSpec se = closing ? none : MoveSpec{half, 0, 2 * half, scan};
         const MoveSpec nx = closing ? MoveSpec{-2, 0, 0, 0} : MoveSpec{half, 1, 2 * half + 1, scan};
         const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : none;
-        pair_step<NCH>(d, c, w, s, ch, se, nx, se_next, pair > 0 ? 1 : 0, (pair > 0 && pre_on && !closing) ? 1 : 0, pair & 1,
+        pair_step<NCH, true>(d, c, w, s, ch, se, nx, se_next, pair > 0 ? 1 : 0, (pair > 0 && pre_on && !closing) ? 1 : 0, pair & 1,
                        closing ? 62 : pair, closing ? 0 : dbg, closing ? 0 : nband, nroles, slot, b);
         if (closing) break;
         const int b_stamp = b - d.b0;
         (void)b_stamp;
         QSTAMP(slot, pair, 8);
-        pair_chain_barrier(ch, b, (unsigned)(nroles + nband), tok0 + (unsigned)pair + 1u, b_stamp, slot, pair);
+        pair_chain_barrier(ch, b, pbase + (unsigned)((pair + 1) * (nroles + nband)), b_stamp, slot, pair);
         QSTAMP(slot, pair, 9);
     }
 }
 
 inline size_t k_move_pa2_lds_bytes(const Dims &d) {
     return sizeof(int) * ((size_t)2 * d.M);
+}
+// k_move_pairs asks for more than half a CU's LDS (160 KB): one workgroup per CU, which its step barrier relies on
+inline size_t k_move_pairs_lds_bytes(const Dims &d) {
+    const size_t need = k_move_pa2_lds_bytes(d), half = 82 * 1024;
+    return need > half ? need : half;
 }
 
 }  // namespace seir

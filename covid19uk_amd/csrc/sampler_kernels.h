@@ -91,9 +91,8 @@ struct Chains {
                                                          // from (band tokens, k_se_chunk's tile flag): the workgroup went on without its data
     int late_fatal;
                                                          //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
-    unsigned *pbar;                                      // [B][PBAR_STRIDE] k_move_pairs: the chain's workgroups that have finished the
-                                                         //     current step (counter, cleared by the last one) and, a line further, the
-                                                         //     token of the last step all of them have finished
+    unsigned *pbar;                                      // [B][PBAR_STRIDE] k_move_pairs: arrivals of the chain's workgroups at the end of a
+                                                         //     step, over all launches (a counter per 128-byte line)
     unsigned *done;                                      // [B][2 TAIL_STRIDE] k_move_pair with band workgroups: token of the launch whose
                                                          //     role r has finished, at [b][r] (a chain's three tokens in its own line)
     unsigned long long *tail;                            // [B][TAIL_STRIDE] k_se_chunk: tiles of the chain that have arrived, over
@@ -1928,8 +1927,25 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
     // run side by side instead of one after the other
     const int span = mv.HI - mv.LO + 1;
     const int total = span > 0 ? mv.n * span : 0;
-    for (int idx = (int)threadIdx.x; idx < total; idx += NT) {
-        const int i0 = idx / span, t = mv.LO + (idx - i0 * span);
+    // A cell's difference is three independent pieces: the S->E term (one or two series of log(1 - e^-r)) and two
+    // differences of binomial coefficients (three log-factorials each).  Where the threads suffice each piece of each cell
+    // gets a thread of its own -- a third of the dependent fp64 chain per thread (the own-rows part of an E->I-type
+    // proposal: 5.4 -> ~3 us); the two binomial pieces are one code path with selected operands, so that their threads
+    // share waves without diverging, and the S->E pieces sit in waves of their own (`base`) where that fits too.
+    // Otherwise (a long occult hull) a thread does all three of its cell, in as many passes as it takes.
+    const int al = (total + WAVE - 1) / WAVE * WAVE;
+    const bool split = 3 * total <= NT;
+    const int base = al + 2 * total <= NT ? al : total;
+    const int nslots = split ? base + 2 * total : total;
+    for (int idx = (int)threadIdx.x; idx < nslots; idx += NT) {
+        int cell = idx, mask = 7;
+        if (split) {
+            if (idx < total) mask = 1;
+            else if (idx < base) continue;
+            else if (idx < base + total) { cell = idx - base; mask = 2; }
+            else { cell = idx - base - total; mask = 4; }
+        }
+        const int i0 = cell / span, t = mv.LO + (cell - i0 * span);
         const int j = mv.m[i0];
         if (j < r_lo || j >= r_hi) continue;
         const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
@@ -1950,59 +1966,72 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
                 for (int i = 0; i < MMAX; ++i) f_moves |= (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]);
             }
             if (dS == 0 && dE == 0 && dI == 0 && dkt == 0 && !f_moves) continue;
-            double coef[MMAX];
-#pragma unroll
-            for (int i = 0; i < MMAX; ++i)
-                coef[i] = (i < mv.n && mv.tgt == 1)
-                              ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
-                              : 0.0;
-            double cfp[MMAX];
-#pragma unroll
-            for (int i = 0; i < MMAX; ++i)
-                cfp[i] = (fp && i < fp->n) ? c.Cstar[(size_t)fp->m[i] * d.Kp0 + j] * c.invN[fp->m[i]] * (double)(-fp->dsrc[i])
-                                           : 0.0;
-            double dF = 0.0;
-#pragma unroll
-            for (int i = 0; i < MMAX; ++i)
-                if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
             const int dk0 = mv.tgt == 0 ? dkt : 0, dk1 = mv.tgt == 1 ? dkt : 0;
-            const double S = w.St[0][rowoff + t], E = w.St[1][rowoff + t], I = w.St[2][rowoff + t];
-            const double kse = w.K[0][rowoff + t], kei = w.K[1][rowoff + t], kir = w.K[2][rowoff + t];
-            const double eb = w.eb[(size_t)b * d.Mp + j];
-            double F = w.F[rowoff + t];
-            if (fp) {                                  // summed first, as apply_f_band does: F + (c0 + c1) is then
-                double dFp = 0.0;                      // bit for bit the value the band will leave in memory
+            if (mask & 1) {
+                double coef[MMAX];
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)
-                    if (i < fp->n && t > fp->lo[i] && t <= fp->hi[i]) dFp += cfp[i];
-                if (dFp != 0.0) F += dFp;
+                    coef[i] = (i < mv.n && mv.tgt == 1)
+                                  ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i])
+                                  : 0.0;
+                double cfp[MMAX];
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    cfp[i] = (fp && i < fp->n) ? c.Cstar[(size_t)fp->m[i] * d.Kp0 + j] * c.invN[fp->m[i]] * (double)(-fp->dsrc[i])
+                                               : 0.0;
+                double dF = 0.0;
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < mv.n && t > mv.lo[i] && t <= mv.hi[i]) dF += coef[i];
+                const double S = w.St[0][rowoff + t], I = w.St[2][rowoff + t], kse = w.K[0][rowoff + t];
+                const double eb = w.eb[(size_t)b * d.Mp + j];
+                double F = w.F[rowoff + t];
+                if (fp) {                                  // summed first, as apply_f_band does: F + (c0 + c1) is then
+                    double dFp = 0.0;                      // bit for bit the value the band will leave in memory
+#pragma unroll
+                    for (int i = 0; i < MMAX; ++i)
+                        if (i < fp->n && t > fp->lo[i] && t <= fp->hi[i]) dFp += cfp[i];
+                    if (dFp != 0.0) F += dFp;
+                }
+                const double ee = ea[t] * eb, psiW = psi * c.W[t];
+                // only the terms the update changes (terms(new) - terms(old) with the rest cancelled): no I->R log
+                const double rr0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
+                // (branch-free series: one straight-line block per case -- device_math.h)
+                if (mv.tgt == 0) {
+                    // S, k_se and E move; the S->E rate (I, F) does not
+                    bool odd = false;
+                    double L0 = log1mexp_series(rr0, ltab, odd);
+                    if (odd) L0 = log1mexp(rr0, ltab);
+                    const double k1 = kse + dk0;
+                    dth += ((k1 != 0.0 ? k1 * L0 : 0.0) - (kse != 0.0 ? kse * L0 : 0.0)) - (double)(dS - dk0) * rr0;
+                } else {
+                    // E, k_ei and I move, and F with them; S and k_se do not
+                    const double rr1 = (ee * ((I + dI) + psiW * (F + dF)) + d.rate_floor) * d.dt;
+                    const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
+                    bool odd = false;
+                    double L1 = log1mexp_series(rr1, ltab, odd), L0 = log1mexp_series(rr0, ltab, odd);
+                    if (odd) { L1 = log1mexp(rr1, ltab); L0 = log1mexp(rr0, ltab); }
+                    dth += (kse != 0.0 ? kse * (L1 - L0) : 0.0) - (S - kse) * (rr1 - rr0) -
+                           (double)dI * r_ir;
+                }
             }
-            const double ee = ea[t] * eb, psiW = psi * c.W[t];
-            // only the terms the update changes (terms(new) - terms(old) with the rest cancelled):
-            // 4 instead of 6 binomial coefficients, no I->R log
-            const double rr0 = (ee * (I + psiW * F) + d.rate_floor) * d.dt;
-            // (branch-free log-factorials and series: one straight-line block per case, its dozen dependent chains
-            // interleaved by the compiler -- device_math.h: lfact_bf)
-            if (mv.tgt == 0) {
-                // S, k_se and E move; the S->E rate (I, F) does not
-                bool odd = false;
-                double L0 = log1mexp_series(rr0, ltab, odd);
-                if (odd) L0 = log1mexp(rr0, ltab);
-                const double k1 = kse + dk0;
-                dth += ((k1 != 0.0 ? k1 * L0 : 0.0) - (kse != 0.0 ? kse * L0 : 0.0)) - (double)(dS - dk0) * rr0;
-                dcn += (lbinom_bf(S + dS, k1, ltab) - lbinom_bf(S, kse, ltab)) + (lbinom_bf(E + dE, kei, ltab) - lbinom_bf(E, kei, ltab)) -
-                       (double)dE * r_ei;
-            } else {
-                // E, k_ei and I move, and F with them; S and k_se do not
-                const double rr1 = (ee * ((I + dI) + psiW * (F + dF)) + d.rate_floor) * d.dt;
-                const double r_ir = w.rir[(size_t)b * d.Tp + t] * d.dt;
-                bool odd = false;
-                double L1 = log1mexp_series(rr1, ltab, odd), L0 = log1mexp_series(rr0, ltab, odd);
-                if (odd) { L1 = log1mexp(rr1, ltab); L0 = log1mexp(rr0, ltab); }
-                dth += (kse != 0.0 ? kse * (L1 - L0) : 0.0) - (S - kse) * (rr1 - rr0) -
-                       (double)dI * r_ir;
-                dcn += (lbinom_bf(E + dE, kei + dk1, ltab) - lbinom_bf(E, kei, ltab)) + (lbinom_bf(I + dI, kir, ltab) - lbinom_bf(I, kir, ltab)) +
-                       (double)dk1 * L_ei - (double)(dE - dk1) * r_ei;
+            // the binomial coefficients: 4 instead of 6 (the third compartment's does not change).  Piece 0: the compartment
+            // that loses or gains by the event count of the target transition (S for an S->E-type update, E for an E->I-type
+            // one), piece 1: the next compartment
+            const int npc = split ? 1 : 2;
+            for (int h = 0; h < npc; ++h) {
+                if (!(mask & 6)) break;
+                const int pc = split ? ((mask & 4) ? 1 : 0) : h;
+                const int cn = mv.tgt + pc;                                    // compartment whose coefficient it is: 0 S, 1 E, 2 I
+                // (the piece differs from thread to thread: a select between two uniform pointers, not an indexed one)
+                const auto *Sp = pc ? w.St[mv.tgt + 1] : w.St[mv.tgt];
+                const auto *Kp = pc ? w.K[mv.tgt + 1] : w.K[mv.tgt];
+                const double n0 = Sp[rowoff + t], k0 = Kp[rowoff + t];
+                const double dn = cn == 0 ? (double)dS : cn == 1 ? (double)dE : (double)dI;
+                const double dk = pc == 0 ? (double)(dk0 + dk1) : 0.0;        // the target transition's events leave compartment mv.tgt
+                double extra = 0.0;
+                if (cn == 1) extra = (double)dk1 * L_ei - (double)(dE - dk1) * r_ei;   // the E->I term of the row (dk1 = 0 for an S->E-type update)
+                dcn += (lbinom_bf(n0 + dn, k0 + dk, ltab) - lbinom_bf(n0, k0, ltab)) + extra;
             }
         }
     }

@@ -944,6 +944,7 @@ struct seir_sampler {
     Chains ch{};
     int record_events = 1;
     bool move_lds_attr = false;       // the event-update kernels were allowed more than 64 KB of dynamic LDS
+    int pairs_lds_attr = 0;           // k_move_pairs was allowed its LDS request (one workgroup per CU): 1 yes, -1 refused
     std::vector<void *> allocs;
     // chains are independent: they are split into groups that run on their own streams
     // so that one group's single-workgroup-per-chain kernels overlap another group's wide ones
@@ -970,6 +971,7 @@ struct seir_sampler {
     unsigned long long leap_steps = 0;   // leapfrog steps done by all k_leap launches so far (what Chains::leap's flags show)
     bool xcd_local = false;       // blocks with the same id mod 8 share an XCD (k_xcc_probe at creation)
     unsigned long long tail_count = 0;   // tiles per chain counted in by all k_se_chunk launches so far (Chains::tail)
+    unsigned pbar_count = 0;      // workgroup arrivals every chain's step counter (Chains::pbar) has seen over all k_move_pairs launches
     int pair_debug = 0;           // debug_pair: test hooks of k_move_pair's handshake (1 late, 2 absent role 1)
     int moves_mode = 0;           // 0 = paired updates (k_move_pair) with the S->E-type proposal pre-drawn one pair ahead -- every pair of a
                                   //     sweep in one launch (k_move_pairs) where band workgroups can be part of it, else one launch per
@@ -1546,8 +1548,11 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         auto pair_fn = nch == 6 ? k_move_pair<6> : nch == 12 ? k_move_pair<12> : k_move_pair<16>;
         auto pa2_fn = nch == 6 ? k_move_pa2<6> : nch == 12 ? k_move_pa2<12> : k_move_pa2<16>;
         auto pairs_fn = nch == 6 ? k_move_pairs<6> : nch == 12 ? k_move_pairs<12> : k_move_pairs<16>;
+        const size_t plds_pairs = k_move_pairs_lds_bytes(d);
+        if (s->pairs_lds_attr == 0)
+            s->pairs_lds_attr = hipFuncSetAttribute((const void *)pairs_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)plds_pairs) == hipSuccess ? 1 : -1;
         if (plds > 64 * 1024 && !s->move_lds_attr) {
-            (void)hipFuncSetAttribute((const void *)pairs_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             (void)hipFuncSetAttribute((const void *)pair_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             (void)hipFuncSetAttribute((const void *)pa2_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
             s->move_lds_attr = true;
@@ -1575,10 +1580,11 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             if (band_in_pair) cp.nrb_d = nband;                          // the band's partial sums: one pair per band workgroup
             // every pair of the sweep and the closing step in ONE launch (k_move_pairs): the grid of a pair launch with band
             // workgroups, resident for the whole sweep -- under the same conditions
-            const bool persistent = band_in_pair && s->moves_mode == 0 && npairs > 0;
+            const bool persistent = band_in_pair && s->moves_mode == 0 && npairs > 0 && s->pairs_lds_attr == 1;
             if (persistent) {
-                hipLaunchKernelGGL(pairs_fn, dim3((3 + nband) * nbk), dim3(MVB), plds, st, dp, ctx->c, ctx->w, cp, s->ch, npairs, 1, nbk,
-                                   s->pair_debug, nband);
+                hipLaunchKernelGGL(pairs_fn, dim3((3 + nband) * nbk), dim3(MVB), plds_pairs, st, dp, ctx->c, ctx->w, cp, s->ch, npairs, 1, nbk,
+                                   s->pair_debug, nband, s->pbar_count);
+                s->pbar_count += (unsigned)(npairs * (3 + nband));           // what every live chain's counter shows after this launch
                 if (s->record_events) fpend_in_record = 1;
                 else hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
                 advanced = 1;
