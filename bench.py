@@ -191,10 +191,11 @@ def main():
         model.set_option(gemm_f32=True)
     burst = max(1, min(K, 50))                    # sweeps per burst of the overlapped-egress measurement
     # (several ranks on ONE GPU -- the CPU-collective rehearsal of the N > 1 path, BENCH_SHARE_GPU=1 -- cannot each have a
-    # whole-chip persistent launch resident: there the leapfrog steps are one launch each)
+    # whole-chip persistent launch resident: there the leapfrog steps and the pairs of event updates are one launch each)
     sampler = ChainSampler(model, MCMC_CONFIG, B, seed=a.seed, first_chain_id=first_chain,
                            trace_capacity=max(K, 2 * burst), record_events="u16",
-                           hmc="chunk-launch" if os.environ.get("BENCH_SHARE_GPU") == "1" and world > 1 else "chunk")
+                           hmc="chunk-launch" if os.environ.get("BENCH_SHARE_GPU") == "1" and world > 1 else "chunk",
+                           moves="paired-launch" if os.environ.get("BENCH_SHARE_GPU") == "1" and world > 1 else "paired")
     sampler.set_state(u0, ev0)
     sampler.set_kernel(step_size=2e-6 if syn else 2e-5)
     # setup (untimed): a short dual-averaging window, then pool the step size over ALL chains
