@@ -1925,16 +1925,26 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
     // the (updated row, day of the hull) pairs are spread over the threads: the rows of a proposal are
     // independent latency chains (loads, then a few hundred dependent fp64 operations per cell), so they
     // run side by side instead of one after the other
-    const int span = mv.HI - mv.LO + 1;
-    const int total = span > 0 ? mv.n * span : 0;
+    // The cells an update can change, enumerated without the gaps of the hull [LO, HI]: the closed windows [lo_k, hi_k]
+    // of its sub-moves, for the row of the sub-move itself (an S->E-type update: nothing else of a row moves) or for
+    // every updated row (an E->I-type update: F moves under all of them in every window); a day that lies in two
+    // windows is taken with the first.  Two event-time moves at distant days made the hull -- and with it the number
+    // of (mostly idle) threads -- several times the days that matter, and kept the split below from applying.
+    int wpre[MMAX + 1];
+    wpre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < MMAX; ++i) wpre[i + 1] = wpre[i] + (i < mv.n ? mv.hi[i] - mv.lo[i] + 1 : 0);
+    const int total_w = wpre[MMAX];
+    const int total = mv.tgt == 1 ? mv.n * total_w : total_w;
     // A cell's difference is three independent pieces: the S->E term (one or two series of log(1 - e^-r)) and two
-    // differences of binomial coefficients (three log-factorials each).  Where the threads suffice each piece of each cell
-    // gets a thread of its own -- a third of the dependent fp64 chain per thread (the own-rows part of an E->I-type
-    // proposal: 5.4 -> ~3 us); the two binomial pieces are one code path with selected operands, so that their threads
-    // share waves without diverging, and the S->E pieces sit in waves of their own (`base`) where that fits too.
-    // Otherwise (a long occult hull) a thread does all three of its cell, in as many passes as it takes.
+    // differences of binomial coefficients (three log-factorials each).  Each piece of each cell is an item of its own
+    // for a thread -- a third of the dependent fp64 chain per item (the own-rows part of an E->I-type proposal:
+    // 5.4 -> ~3 us) -- as long as the items are at most two per thread; the two binomial pieces are one code path with
+    // selected operands, so that their threads share waves without diverging, and the S->E pieces sit in waves of
+    // their own (`base`) where that fits too.  Otherwise (a long occult hull) a thread does all three pieces of its
+    // cell, in as many passes as it takes: one round of loads per cell instead of three.
     const int al = (total + WAVE - 1) / WAVE * WAVE;
-    const bool split = 3 * total <= NT;
+    const bool split = 3 * total <= 2 * NT;
     const int base = al + 2 * total <= NT ? al : total;
     const int nslots = split ? base + 2 * total : total;
     for (int idx = (int)threadIdx.x; idx < nslots; idx += NT) {
@@ -1945,7 +1955,18 @@ __device__ __forceinline__ void own_rows_delta(const Dims &d, const Consts &c, c
             else if (idx < base + total) { cell = idx - base; mask = 2; }
             else { cell = idx - base - total; mask = 4; }
         }
-        const int i0 = cell / span, t = mv.LO + (cell - i0 * span);
+        int i0 = 0, pos = cell;
+        if (mv.tgt == 1) { i0 = cell / total_w; pos = cell - i0 * total_w; }
+        int k = 0, p0 = 0;
+#pragma unroll
+        for (int i = 1; i < MMAX; ++i)
+            if (i < mv.n && pos >= wpre[i]) { k = i; p0 = wpre[i]; }
+        const int t = mv.lo[k] + (pos - p0);
+        if (mv.tgt == 0) i0 = k;
+        bool dup = false;
+#pragma unroll
+        for (int i = 0; i < MMAX - 1; ++i) dup |= (mv.tgt == 1 && i < k && t >= mv.lo[i] && t <= mv.hi[i]);
+        if (dup) continue;
         const int j = mv.m[i0];
         if (j < r_lo || j >= r_hi) continue;
         const size_t rowoff = ((size_t)b * d.Mp + j) * d.Tp;
