@@ -200,7 +200,12 @@ typedef struct {
                                        under the same condition); 1: one proposal kernel per update (k_move_pa2) --
                                        kept as a cross-check; 2: as 4 without the pre-draw; 3: as 4 with the band part
                                        of the E->I-type log-ratio always as its own launch (k_move_delta).
-                                       Same draws in all five */
+                                       Same draws in all five.  The persistent forms (this one and hmc_mode 0) need
+                                       every workgroup of their launch resident at once: one sampler at a time per GPU
+                                       -- two such launches from different streams or processes can each hold part of
+                                       the chip and wait for the rest; their waits are bounded, the sampler then fails
+                                       loudly at the next read of the trace (seir_sampler_pair_timeouts), and modes 4 /
+                                       hmc_mode 3 are the forms for a shared GPU */
     int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks; all L-1 of them in ONE persistent launch
                                        (k_leap: the gradient tiles keep their cells in registers over the steps, tiles and
                                        chunk roles hand each other the partial sums / the next tables through the XCD's L2)
