@@ -1034,13 +1034,84 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     (void)sh_cn;
 }
 
+// The closing step of k_move_pairs for a band workgroup: what k_record (or k_apply_fpend) did as a launch of its own at
+// the end of a sweep -- the F band of the sweep's last accepted E->I-type update applied to this workgroup's rows, and
+// (record != 0) those rows' events written to the trace in the reference's [M][T][3] order.  Role 0 raises token 4 when
+// the pending update is decided (Chains::fpend) and token 5 when its rows are in the planes; the workgroup's L1 was
+// emptied when the step began and it has loaded nothing of the planes since: plain loads.
+// sweep0: the chain's sweep counter as the launch found it (role 0 advances it in this very step).
+__device__ __forceinline__ void pair_band_finish(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
+                                                 const Chains &ch, int b, int bx, int nband, unsigned token, unsigned sweep0,
+                                                 int record) {
+    __shared__ Move fp;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                          // (see pair_step)
+    const int wave = tid >> 6, lane = tid & 63;
+    const unsigned *done = ch.done + (size_t)b * 2 * TAIL_STRIDE;
+    const int rpb = (d.M + nband - 1) / nband;
+    const int r_lo = bx * rpb, r_hi = min(d.M, r_lo + rpb);
+    if (tid == 0) wait_token(done + 4, token, ch.late + ch.late_fatal + b);
+    __syncthreads();
+    move_copy_l2(&fp, ch.fpend + b, 128);
+    if (tid == 0) wait_token(done + 5, token, ch.late + ch.late_fatal + b);
+    __syncthreads();
+    const unsigned slot = sweep0 - ch.slot0[0];
+    for (int m = r_lo + wave; m < r_hi; m += MVW) {
+        if (fp.valid == 1) {
+            double coef[MMAX];
+#pragma unroll
+            for (int i = 0; i < MMAX; ++i)
+                coef[i] = i < fp.n ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + m] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+            double *Fr = w.F + ((size_t)b * d.Mp + m) * d.Tp;
+            for (int t = fp.LO + lane; t <= fp.HI; t += WAVE) {
+                double dF = 0.0;
+#pragma unroll
+                for (int i = 0; i < MMAX; ++i)
+                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dF += coef[i];
+                if (dF != 0.0) Fr[t] += dF;
+            }
+        }
+        if (!record || slot >= (unsigned)s.cap) continue;
+        // (k_record's copy: one wave per row, lanes over days, four 64-day pieces of the three planes in flight)
+        const size_t o0 = (((size_t)slot * s.B + b) * d.M + m) * d.T * 3;
+        int *out = (int *)ch.tr_events + o0;
+        unsigned short *out16 = (unsigned short *)ch.tr_events + o0;
+        const size_t q0 = ((size_t)b * d.Mp + m) * d.Tp;
+        for (int t0 = 0; t0 < d.T; t0 += 4 * WAVE) {
+            int k0[4], k1[4], k2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                     // pads exist up to Tp: unconditional loads
+                const int t = t0 + j * WAVE + lane;
+                const bool in = t < d.Tp;
+                k0[j] = in ? w.K[0][q0 + t] : 0;
+                k1[j] = in ? w.K[1][q0 + t] : 0;
+                k2[j] = in ? w.K[2][q0 + t] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + j * WAVE + lane;
+                if (t < d.T) {
+                    if (s.ev16) {                                   // uniform
+                        if ((unsigned)(k0[j] | k1[j] | k2[j]) > 0xffffu) ch.ev_overflow[0] = 1u;     // reported by the read
+                        out16[t * 3 + 0] = (unsigned short)k0[j]; out16[t * 3 + 1] = (unsigned short)k1[j];
+                        out16[t * 3 + 2] = (unsigned short)k2[j];
+                    } else {
+                        out[t * 3 + 0] = k0[j]; out[t * 3 + 1] = k1[j]; out[t * 3 + 2] = k2[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One pair of updates by the workgroup in `slot` of chain b: the body of k_move_pair (one launch per pair) and of one
 // step of k_move_pairs (every pair of a sweep in one launch).  nroles: role slots of the grid (the speculative roles in
 // the low slots, role 0 in the last), nband: band workgroups per chain that take part in THIS pair (0: none).
 template <int NCH, bool SOLO>
 __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s, const Chains &ch,
                                           MoveSpec se, MoveSpec next, MoveSpec se_next, int have_prev, int have_pre, int pbuf,
-                                          int lidx, int dbg, int nband, int nroles, int slot, int b) {
+                                          int lidx, int dbg, int nband, int nroles, int slot, int b, int fin = 0,
+                                          unsigned sweep0 = 0u) {
     extern __shared__ __attribute__((aligned(16))) int dyn_i[];                     // rg [M] | rt [M]
     __shared__ MvShared sm_se, sm_nx;
     __shared__ Move pendA, pendB;
@@ -1058,6 +1129,10 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
     QSTAMP(slot, lidx, 0);
     if (slot >= nroles) {                                  // band workgroups (the highest block ids)
         if (nband == 0) return;
+        if (fin) {                                         // the closing step of k_move_pairs: they finish the sweep
+            pair_band_finish(d, c, w, s, ch, b, slot - nroles, nband, sweep0 * 64u + (unsigned)lidx + 1u, sweep0, fin & 2);
+            return;
+        }
         const unsigned tok = ch.sweep[b] * 64u + (unsigned)lidx + 1u;
         const bool r1 = next.kind >= 0 && nroles >= 2, r2 = se_next.kind >= 0 && nroles == 3;
         pair_band_block<SOLO>(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1, slot, lidx);
@@ -1292,6 +1367,12 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
     }
     PSTAMP(1);
     QSTAMP(slot, lidx, 1);
+    if (fin && nband > 0) {
+        // closing step of k_move_pairs: the band workgroups finish the sweep (pair_band_finish) once the planes are final
+        __syncthreads();                                   // mv_apply_rows ends drained; the trace stores need not be
+        if (tid == 0)
+            __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 5, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- (2) the whole S->E-type update
     bool se_acc = false;
     if (do_se) {
@@ -1491,12 +1572,15 @@ __device__ __forceinline__ void pair_chain_barrier(const Chains &ch, int b, unsi
 
 template <int NCH>
 __global__ __launch_bounds__(MVB) void k_move_pairs(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int npairs, int pre_on,
-                                                    int nbk, int dbg, int nband, unsigned pbase) {
+                                                    int nbk, int dbg, int nband, unsigned pbase, int fin) {
     debug_skew(d);
     const int nroles = (int)gridDim.x / nbk - nband, slot = (int)blockIdx.x / nbk;   // 3 roles
     const int b = d.b0 + (int)blockIdx.x - slot * nbk;
     if (d.nlive > 0 && (int)blockIdx.x - slot * nbk >= d.nlive) return;             // a chain of the layout that does not exist
     const MoveSpec none{-1, 0, 0, 0};
+    // fin: in the closing step the band workgroups apply the F band of the last accepted E->I-type update (1) and write
+    // the sweep's events to the trace (3): k_apply_fpend's / k_record's work, without their launch
+    const unsigned sweep0 = ch.sweep[b];
     for (int pair = 0; pair <= npairs; ++pair) {
         // as enqueue_sweep launches k_move_pair: scan = pair / 2, the first half of a scan is the event-time moves, the second
         // the occults; step npairs is the closing one: role 0 finalizes the last E->I-type proposal and advances the sweep counter
@@ -1507,7 +1591,7 @@ __global__ __launch_bounds__(MVB) void k_move_pairs(Dims d, Consts c, Work w, Sa
         const MoveSpec nx = closing ? MoveSpec{-2, 0, 0, 0} : MoveSpec{half, 1, 2 * half + 1, scan};
         const MoveSpec se_next = pre ? MoveSpec{nh, 0, 2 * nh, nscan} : none;
         pair_step<NCH, true>(d, c, w, s, ch, se, nx, se_next, pair > 0 ? 1 : 0, (pair > 0 && pre_on && !closing) ? 1 : 0, pair & 1,
-                       closing ? 62 : pair, closing ? 0 : dbg, closing ? 0 : nband, nroles, slot, b);
+                       closing ? 62 : pair, closing ? 0 : dbg, (closing && !fin) ? 0 : nband, nroles, slot, b, closing ? fin : 0, sweep0);
         if (closing) break;
         const int b_stamp = b - d.b0;
         (void)b_stamp;

@@ -1537,7 +1537,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     // [part 1] MultiScan(n_scans, Gibbs[move S->E, move E->I, occult S->E, occult E->I]):
     // per update [finalize previous | propose] then the log-ratio over the touched cells
     Dims d = l.d;
-    int advanced = 0, fpend_in_record = 0;
+    int advanced = 0, fpend_in_record = 0, recorded = 0;
     {
         const bool aff = (l.affinity & 2) && xcd_affinity_applies(c.nrb_d, nb);
         d.aff_nb = aff ? nb : 0;
@@ -1582,12 +1582,12 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             // workgroups, resident for the whole sweep -- under the same conditions
             const bool persistent = band_in_pair && s->moves_mode == 0 && npairs > 0 && s->pairs_lds_attr == 1;
             if (persistent) {
+                // (its closing step also does what k_apply_fpend / k_record are launched for in the other forms)
                 hipLaunchKernelGGL(pairs_fn, dim3((3 + nband) * nbk), dim3(MVB), plds_pairs, st, dp, ctx->c, ctx->w, cp, s->ch, npairs, 1, nbk,
-                                   s->pair_debug, nband, s->pbar_count);
+                                   s->pair_debug, nband, s->pbar_count, s->record_events ? 3 : 1);
                 s->pbar_count += (unsigned)(npairs * (3 + nband));           // what every live chain's counter shows after this launch
-                if (s->record_events) fpend_in_record = 1;
-                else hipLaunchKernelGGL(k_apply_fpend, gm, dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch);
                 advanced = 1;
+                recorded = 1;
             }
             for (int scan = 0; scan < (persistent ? 0 : c.n_scans); ++scan)
                 for (int half = 0; half < 2; ++half) {
@@ -1633,7 +1633,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         }
     }
     d.aff_nb = 0;
-    if (s->record_events)
+    if (s->record_events && !recorded)
         hipLaunchKernelGGL(k_record, dim3((d.M + 3) / 4, nb), dim3(256), 0, st, d, ctx->c, ctx->w, c, s->ch, advanced,
                            fpend_in_record);
     if (!advanced) hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);
