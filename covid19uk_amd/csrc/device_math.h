@@ -60,6 +60,18 @@ __device__ __forceinline__ double fast_log(double x, const double2 *tab) {
     return fma(kd, 0.69314718055994529, tc.y) + fma(kd, 2.3190468138462996e-17, p);
 }
 
+__device__ __forceinline__ double fast_rcp(double x);
+// softplus(x) = max(x, 0) + log1p(e^-|x|) in ONE path for every lane (libm's two-sided form runs both sides when the
+// lanes' signs differ) with the table logarithm: log1p(e) = log(w) + (e - (w - 1)) / w, w = fl(1 + e) -- the rounding of
+// 1 + e given back, so the result is good to the last bit or two for any e in (0, 1].  For the chunk roles of a leapfrog
+// step, where psi and sigma_space of the new point sit on the step's critical path (the stage kernels and the
+// parameter tables, once per launch, keep libm's: the two agree to ~1e-16 relative).
+__device__ __forceinline__ double softplus_tab(double x, const double2 *tab) {
+    const double e = exp(-fabs(x));
+    const double wv = 1.0 + e;
+    return fmax(x, 0.0) + (fast_log(wv, tab) + (e - (wv - 1.0)) * fast_rcp(wv));
+}
+
 // reciprocal of a positive normal double: v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);

@@ -1186,6 +1186,9 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         // ------------------------------------------------------------------ M-chunk
         const int ci = bx - ntc, m = ci * WAVE + lane;
         const bool own = m < M;
+        // the logarithm's table, for the softplus of the new psi and sigma_space (softplus_tab): in LDS before the wait
+        ltab[lane] = c.logtab[lane];
+        ltab[lane + WAVE] = c.logtab[lane + WAVE];
         // (first step of a folded trajectory: the spatial effects of the start point are q's own)
         const double *spr = first ? qs0 + oM : w.sp + ((size_t)b * 2 + par) * d.Mp;
         double *spw = w.sp + ((size_t)b * 2 + (par ^ 1)) * d.Mp;
@@ -1202,7 +1205,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             // (that block is being rewritten by the first M-chunk of this very step)
             const double e0_ = 2.220446049250313e-16;
             const double ux_ = lane == 0 ? u0 : u1;
-            const double spx_ = softplus(ux_);
+            const double spx_ = softplus_tab(ux_, ltab);
             const double sgx_ = cold_exp(ux_ - spx_);
             psi = lane_value(spx_, 0) + e0_; sig = lane_value(spx_, 1) + e0_;
             s0 = lane_value(sgx_, 0); s1 = lane_value(sgx_, 1);
@@ -1338,7 +1341,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         // both softplus in one pass: lane 0 takes u0, the other lanes u1
         const double e0 = 2.220446049250313e-16;
         const double ux = lane == 0 ? u0n : u1n;
-        const double spx = softplus(ux);
+        const double spx = softplus_tab(ux, ltab);
         const double sgx = cold_exp(ux - spx);             // sigmoid(u) = exp(u - softplus(u))
         const double psin = lane_value(spx, 0) + e0, sign = lane_value(spx, 1) + e0;
         const double s0n = lane_value(sgx, 0), s1n = lane_value(sgx, 1);
