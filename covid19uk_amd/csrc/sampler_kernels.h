@@ -91,6 +91,9 @@ struct Chains {
                                                          // from (band tokens, k_se_chunk's tile flag): the workgroup went on without its data
     int late_fatal;
                                                          //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
+    double *finpart;                                     // [B][32][4] k_leap with the trajectory's end folded in: per role, its parts of the
+                                                         //     end point's kinetic energy and log-probability (and, by T-chunk 0, the
+                                                         //     running-variance count), for the accept test every role then makes
     unsigned *pbar;                                      // [B][PBAR_STRIDE] k_move_pairs: arrivals of the chain's workgroups at the end of a
                                                          //     step, over all launches (a counter per 128-byte line)
     unsigned *done;                                      // [B][2 TAIL_STRIDE] k_move_pair with band workgroups: token of the launch whose
@@ -959,8 +962,11 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
     // read from Chains::q0 (and psi, sigma, the sigmoids formed again from it): the other roles of this step are already
     // writing the next position to q and the scalar block.  2 = the step after it, whose first T-chunk adds the parts up
     // (every role of step one has finished)
-    const bool first = PERS && traj == 1;
-    const double kick = first ? 0.5 * eps : eps;
+    // 3 = the trajectory's LAST half kick (k_hmc_step<2>'s in the other forms): nothing of the position moves; the role leaves
+    // its parts of the end point's kinetic energy and log-probability (Chains::finpart) for the accept test, which every
+    // role makes for itself once all of them have counted in (hmc_final_apply)
+    const bool first = PERS && traj == 1, fin = PERS && traj == 3;
+    const double kick = (first || fin) ? 0.5 * eps : eps;
     const int oT = 6 - 1, oM = 6 + T - 1;
     const double *TS = w.TS + (size_t)b * ntile * 4;
     const double *gr = w.gst + ((size_t)b * 2 + par) * GST_N;
@@ -1068,6 +1074,18 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         }
         const double ng0s = wave_sum(ng0p), ng1s = wave_sum(ng1p);
         if (probe) { asm volatile("" :: "v"(ng0s), "v"(ng1s)); }
+        double irl_fin = 0.0;
+        if (fin) {
+            // the I->R term itself at the end point's rates (the accept test's log-probability), this chunk's days
+            double xl = 0.0;
+            if (t < T) {
+                const double rr_ = exp(g0 + g1 * wd_t);
+                double L, inv;
+                l1me_inv_wide(rr_ * d.dt, L, inv, ltab);
+                xl = (kir_t != 0.0 ? kir_t * L : 0.0) - dir_t * (rr_ * d.dt);
+            }
+            irl_fin = wave_sum(xl);
+        }
         CPROBE(12);                                         // I->R part done
         wait();
         // ---- from here on: this step's partial sums
@@ -1155,6 +1173,17 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const double pn = own ? pm + kick * g : 0.0;
         const double an = own ? alpha + eps * v * pn : 0.0;
         const double pa0n = pa0 + kick * (allB - a0 / 100.0), a0n = a0 + eps * va0 * pa0n;
+        if (fin) {
+            double kin = wave_sum(own ? 0.5 * v * pn * pn : 0.0);
+            if (ci == 0) kin += (0.5 * vg0 * pg0n * pg0n + 0.5 * vg1 * pg1n * pg1n) + 0.5 * va0 * pa0n * pa0n;
+            const double a2 = wave_sum(alpha * alpha);
+            if (lane == 0) {
+                double *fpw = ch.finpart + ((size_t)b * 32 + bx) * 4;
+                fpw[0] = kin; fpw[1] = irl_fin; fpw[2] = a2;
+                if (ci == 0) fpw[3] = ch.hs[(size_t)b * NHS + HS_RV_N];      // (read by every role behind the hand-off; advanced by this one)
+            }
+            return;
+        }
         if (first) {
             double kin = wave_sum(own ? 0.5 * v * pm * pm : 0.0);
             if (ci == 0) kin += (0.5 * vg0 * pg0 * pg0 + 0.5 * vg1 * pg1 * pg1) + 0.5 * va0 * pa0 * pa0;
@@ -1333,6 +1362,16 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const double p0n = p0 + kick * ((ps + 2.0 / psi - 10.0) * s0 + (1.0 - s0)), u0n = u0 + eps * v0 * p0n;
         const double p1n = p1 + kick * ((rs - sig / 0.01) * s1 + (1.0 - s1)), u1n = u1 + eps * v1 * p1n;
         const double p2n = p2 + kick * (rl - beta), betan = beta + eps * v2 * p2n;
+        if (fin) {
+            double kin = wave_sum(own ? 0.5 * v * pn * pn : 0.0);
+            if (ci == 0) kin += (0.5 * v0 * p0n * p0n + 0.5 * v1 * p1n * p1n) + 0.5 * v2 * p2n * p2n;
+            const double sqs = wave_sum(own ? sm * Qs : 0.0);
+            if (lane == 0) {
+                double *fpw = ch.finpart + ((size_t)b * 32 + bx) * 4;
+                fpw[0] = kin; fpw[1] = 0.0; fpw[2] = sqs;
+            }
+            return;
+        }
         if (first) {
             double kin = wave_sum(own ? 0.5 * v * pm * pm : 0.0);
             if (ci == 0) kin += (0.5 * v0 * p0 * p0 + 0.5 * v1 * p1 * p1) + 0.5 * v2 * p2 * p2;
@@ -1359,6 +1398,161 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
     }
 }
 
+
+// The end of a trajectory inside k_leap (fold bit 2): what k_hmc_step<2> does after its half kick, by the chunk roles and
+// without another hand-off.  Every role of the last step has left its parts (Chains::finpart) and counted in; each role --
+// one wave -- now adds them up in the same order, so all of them arrive at the same log-ratio and, from the same Philox
+// draw, at the same decision, and each applies it to the entries it owns: on acceptance q stays (and becomes q0, the next
+// trajectory's start point; the tables are the end point's already), on rejection q goes back to q0 and the role
+// rebuilds its share of the tables from it.  The first T-chunk also does the bookkeeping of the step (accept flag, log-probability,
+// dual averaging, trace row), T-chunk 0 / M-chunk 0 the global parameters.  Nothing a role writes here is read by another
+// role of this launch: they read finpart, the tiles' parts, the globals' block of the step (Work::gst), q0 and the start
+// point's energy, none of which is written.
+// (Sums are associated differently from k_hmc_step<2>'s block reductions: same draws up to rounding.)
+template <int NTC>
+__device__ __forceinline__ void hmc_final_apply(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
+                                                const Chains &ch, int par, int bx, int b, int lane) {
+    auto LDQ = [](const double *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const int T = d.T, M = d.M, ntc = NTC > 0 ? NTC : d.ntc, nroles = ntc + d.Mp / WAVE, ntile = d.nmt * ntc;
+    const int oT = 6 - 1, oM = 6 + T - 1;
+    double *q = ch.q + (size_t)b * d.Pp, *q0 = ch.q0 + (size_t)b * d.Pp, *var = ch.var + (size_t)b * d.Pp;
+    double *hs = ch.hs + (size_t)b * NHS, *sc = w.scal + (size_t)b * NSCAL;
+    const double *gr = w.gst + ((size_t)b * 2 + par) * GST_N;
+    const double *fp = ch.finpart + (size_t)b * 32 * 4;
+    const double e0 = 2.220446049250313e-16;
+    // ---- the sums: the same in every role
+    const bool isr = lane < nroles, ist = lane < ntc;
+    const double f0 = LDQ(fp + (isr ? lane : 0) * 4), f1 = LDQ(fp + (isr ? lane : 0) * 4 + 1), f2 = LDQ(fp + (isr ? lane : 0) * 4 + 2);
+    const double n_old = LDQ(fp + 3);
+    double lk = 0.0;
+    for (int i = lane; i < ntile; i += WAVE) lk += LDQ(w.Lpart + (size_t)b * ntile + i);
+    const double u0 = LDQ(gr + 0), u1 = LDQ(gr + 1), beta = LDQ(gr + 2), g0 = LDQ(gr + 3), g1 = LDQ(gr + 4), a0 = LDQ(gr + 5),
+                 psi = LDQ(gr + 12), sig = LDQ(gr + 13);
+    const double lp0 = LDQ(hs + HS_LP0), k0 = LDQ(hs + HS_K0);
+    const double K1 = wave_sum(isr ? f0 : 0.0), irl = wave_sum(ist ? f1 : 0.0), a2 = wave_sum(ist ? f2 : 0.0),
+                 sqs = wave_sum((isr && !ist) ? f2 : 0.0);
+    lk = wave_sum(lk);
+    // model_spec.py:140-198 and the bijector's Jacobian (inference.py:555-557), as k_hmc_step writes them
+    double prior = d.prior_const;
+    prior += -0.5 * a0 * a0 / 100.0 - 0.5 * beta * beta;
+    prior += 2.0 * cold_log(psi) - 10.0 * psi;
+    prior += -0.5 * a2 / (0.005 * 0.005);
+    prior += -sig * sig / 0.02;
+    prior += -0.5 * sqs;
+    prior += -0.5 * (g0 * g0 + g1 * g1) / 1.0e4;
+    const double jac = (u0 - (psi - e0)) + (u1 - (sig - e0));
+    const double lp_theta = (lk + irl) + prior + jac;
+    const double log_ratio = (lp_theta - lp0) - (K1 - k0);
+    const RngKey key = rng_key(s, ch, b);
+    double ua, ub;
+    rng_uniform2(key, RS_HMC_ACCEPT, 0u, ua, ub);
+    const bool acc = cold_log(ua) < log_ratio && !(s.disable_mask & 1);            // NaN compares false -> reject
+    const unsigned slot = ch.sweep[b] - ch.slot0[0];
+    double *tr = slot < (unsigned)s.cap ? ch.tr_theta + ((size_t)slot * s.B + b) * d.P : nullptr;
+    const double n1 = n_old + 1.0;
+    auto welford = [&](int i, double x) {                      // running variance with the new state (ddof 0)
+        double *mean = ch.rv_mean + (size_t)b * d.Pp, *m2 = ch.rv_m2 + (size_t)b * d.Pp;
+        const double dlt = x - mean[i];
+        const double mu = mean[i] + dlt / n1;
+        const double ss = m2[i] + dlt * (x - mu);
+        mean[i] = mu; m2[i] = ss;
+        var[i] = ss / n1;
+    };
+    if (bx < ntc) {
+        // ------------------------------------------------------------------ T-chunk
+        const int ci = bx, t = ci * WAVE + lane;
+        const bool own = t >= 1 && t < T;
+        const double xq = own ? (acc ? LDQ(q + oT + t) : q0[oT + t]) : 0.0;
+        if (own) {
+            if (acc) q0[oT + t] = xq; else q[oT + t] = xq;
+            if (s.adapt_mass) welford(oT + t, xq);
+            if (tr) tr[oT + t] = xq;
+        }
+        double ga0 = a0, gg0 = g0, gg1 = g1;                   // alpha_0, gamma_0, gamma_1 of the state the chain is left in
+        if (!acc) {
+            // back at the start point: this chunk's days of exp(a_t) and of the I->R rate from q0 (the sum of alpha over the
+            // chunks before this one from their entries, as the first step of a trajectory forms it)
+            ga0 = q0[5]; gg0 = q0[3]; gg1 = q0[4];
+            double pre = 0.0;
+            for (int cc = 0; cc < ci; ++cc) {
+                const int tt = cc * WAVE + lane;
+                pre += wave_sum((tt >= 1 && tt < T) ? q0[oT + tt] : 0.0);
+            }
+            const double a_t = ga0 + pre + wave_incl_scan(xq, lane);
+            if (t < T) {
+                w.acur[(size_t)b * d.Tp + t] = a_t;
+                w.ea[(size_t)b * d.Tp + t] = exp(a_t);
+                w.rir[(size_t)b * d.Tp + t] = exp(gg0 + gg1 * c.wd[t]);
+            }
+        }
+        if (ci == 0 && lane == 0) {
+            if (acc) { q0[3] = gg0; q0[4] = gg1; q0[5] = ga0; }
+            else { q[3] = gg0; q[4] = gg1; q[5] = ga0; sc[SC_G0] = gg0; sc[SC_G1] = gg1; sc[SC_A0] = ga0; }
+            if (s.adapt_mass) { welford(3, gg0); welford(4, gg1); welford(5, ga0); hs[HS_RV_N] = n1; }
+            if (tr) { tr[3] = gg0; tr[4] = gg1; tr[5] = ga0; }
+            if (acc) { sc[SC_PRIOR] = prior; sc[SC_JAC] = jac; }
+            // the step's bookkeeping (k_hmc_step<2>)
+            const double eps = hs[HS_EPS];
+            hs[HS_ACC] = acc ? 1.0 : 0.0;
+            hs[HS_LOGACC] = log_ratio;
+            const double lpt = acc ? lp_theta : lp0;
+            hs[HS_LP_THETA] = lpt;
+            double eps_traced = eps;
+            if (s.adapt_step) {                       // dual averaging (Hoffman & Gelman alg. 5, TFP defaults)
+                const double a = isfinite(log_ratio) ? fmin(1.0, cold_exp(log_ratio)) : 0.0;
+                const double prev_step = hs[HS_DA_STEP];
+                const double n = prev_step + 1.0;
+                const double err = hs[HS_DA_ERR] + s.target_accept - a;
+                const double log_step = hs[HS_DA_MU] - err * sqrt(n) / ((n + 10.0) * 0.05);
+                const double eta = cold_exp(-0.75 * cold_log(n));
+                const double log_avg = eta * log_step + (1.0 - eta) * hs[HS_DA_LOGAVG];
+                hs[HS_DA_ERR] = err; hs[HS_DA_STEP] = n; hs[HS_DA_LOGAVG] = log_avg;
+                if (prev_step <= (double)s.n_adapt) {
+                    eps_traced = cold_exp(prev_step < (double)s.n_adapt ? log_step : log_avg);
+                    hs[HS_EPS] = eps_traced;
+                }
+            }
+            if (slot < (unsigned)s.cap) {
+                double *th = ch.tr_hmc + ((size_t)slot * s.B + b) * 3;
+                th[0] = acc ? 1.0 : 0.0;
+                th[1] = lpt + hs[HS_LP_CONST];
+                th[2] = eps_traced;
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ M-chunk
+        const int ci = bx - ntc, m = ci * WAVE + lane;
+        const bool own = m < M;
+        const double xq = own ? (acc ? LDQ(q + oM + m) : q0[oM + m]) : 0.0;
+        double bu0 = u0, bu1 = u1, bbeta = beta, bpsi = psi, bsig = sig;
+        if (own) {
+            if (acc) q0[oM + m] = xq; else q[oM + m] = xq;
+            if (s.adapt_mass) welford(oM + m, xq);
+            if (tr) tr[oM + m] = xq;
+        }
+        if (!acc) {
+            // back at the start point: psi, sigma_space and the rows' exp(b_m)/N_m from q0
+            bu0 = q0[0]; bu1 = q0[1]; bbeta = q0[2];
+            const double ux = lane == 0 ? bu0 : bu1;
+            // (as the role that left this point formed them, so that a rejected draw repeats the previous one to the bit;
+            // the table straight from memory: a rare path)
+            const double spx = softplus_tab(ux, c.logtab);
+            const double sgx = cold_exp(ux - spx);
+            bpsi = lane_value(spx, 0) + e0; bsig = lane_value(spx, 1) + e0;
+            const double s0n = lane_value(sgx, 0), s1n = lane_value(sgx, 1);
+            if (own) w.eb[(size_t)b * d.Mp + m] = exp(bbeta * c.la[m] + bsig * xq) * c.invN[m];
+            if (ci == 0 && lane == 0) {
+                q[0] = bu0; q[1] = bu1; q[2] = bbeta;
+                sc[SC_PSI] = bpsi; sc[SC_SIG] = bsig; sc[SC_BETA] = bbeta; sc[SC_S0] = s0n; sc[SC_S1] = s1n;
+            }
+        }
+        if (ci == 0 && lane == 0) {
+            if (acc) { q0[0] = bu0; q0[1] = bu1; q0[2] = bbeta; }
+            if (s.adapt_mass) { welford(0, bu0); welford(1, bu1); welford(2, bbeta); }
+            if (tr) { tr[0] = bpsi; tr[1] = bsig; tr[2] = bbeta; }
+        }
+    }
+}
 
 template <int NTC>
 __global__ __launch_bounds__(WAVE) void k_hmc_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par) {
@@ -1773,7 +1967,10 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
     unsigned long long *cnt2 = LEAP_CNT2(b);
     const unsigned long long *flag2 = LEAP_FLAG2(b, role & (LEAP_NSH - 1));
     unsigned *late = ch.late + ch.late_fatal + b;
-    const int nrole_steps = nsteps - ((fold & 2) ? 1 : 0);      // nobody follows the end point's gradient here: k_hmc_step<2> does
+    // fold bit 2 (value 4): the roles follow the end point's gradient as well -- the last half kick and the accept test
+    // (hmc_chunk_role's traj 3, hmc_final_apply); without it k_hmc_step<2> does that as a launch of its own
+    const bool fin_in = (fold & 4) != 0;
+    const int nrole_steps = nsteps - (((fold & 2) && !fin_in) ? 1 : 0);
     for (int it = 0; it < nrole_steps; ++it) {
         // nothing of a role lives across the steps: without this the compiler hoists the step-invariant loads of the role
         // (variances, V(t), the I->R statistics, CAR rows ...) out of the loop and spills 500+ bytes per lane to hold them
@@ -1820,7 +2017,7 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
 #else
         nullptr,
 #endif
-        gbuf, (fold & 1) ? (it == 0 ? 1 : it == 1 ? 2 : 0) : 0);
+        gbuf, (fin_in && it == nsteps - 1) ? 3 : (fold & 1) ? (it == 0 ? 1 : it == 1 ? 2 : 0) : 0);
         RPROBE(2);                                               // stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this role's stores are in the XCD's L2
         RPROBE(3);
@@ -1832,6 +2029,11 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
                 __hip_atomic_store(LEAP_FLAG2(b, threadIdx.x), rstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (threadIdx.x == 0) { LSTAMP_MIN(6); LSTAMP_MAX(7); }
             RPROBE(4);                                           // counted in
+        }
+        if (fin_in && it == nsteps - 1) {
+            // the trajectory's end: once every role has left its parts, each makes the accept test and applies it to its entries
+            leap_wait(flag2, rstep, late);
+            hmc_final_apply<NTC>(d, c, w, s, ch, par, role, b, lane_op);
         }
     }
 }

@@ -965,7 +965,8 @@ struct seir_sampler {
     // seir_sampler_time_leapfrog: HIP events around the inner leapfrog steps of each sweep while it is on
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after)
     int prof_i = -1, prof_launches = 0, prof_evals = 0;  // next pair to record (-1: off); launches / gradient evaluations of the section in the last sweep
-    bool hmc_fold = true;         // hmc_mode 0: the trajectory's first step and both end-point gradients inside k_leap as well
+    bool hmc_fold = true;         // hmc_mode 0 / 5: the trajectory's first step and both end-point gradients inside k_leap as well
+    bool hmc_end = true;          // hmc_mode 0: ... and its last half kick, accept test, adaptation and trace (5: k_hmc_step<2> does those)
     bool vt_dirty = true;         // Work::Vt does not match Chains::var (set_kernel / set_adaptation / creation)
     unsigned long long leap_rsteps = 0;  // steps the ROLES of k_leap have done over all launches (the tiles do one more per folded launch)
     unsigned long long leap_steps = 0;   // leapfrog steps done by all k_leap launches so far (what Chains::leap's flags show)
@@ -1036,8 +1037,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
     if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
-    if (ds->moves_mode < 0 || ds->moves_mode > 4 || ds->hmc_mode < 0 || ds->hmc_mode > 4)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..4");
+    if (ds->moves_mode < 0 || ds->moves_mode > 4 || ds->hmc_mode < 0 || ds->hmc_mode > 5)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..5");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
@@ -1061,9 +1062,10 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     s->use_graph = ds->use_graph != 0;
     s->pair_debug = ds->debug_pair;
     s->hmc_chunked = ds->hmc_mode != 1;
-    s->hmc_tail = ds->hmc_mode == 0 || ds->hmc_mode == 3 || ds->hmc_mode == 4;
-    s->hmc_leap = ds->hmc_mode == 0 || ds->hmc_mode == 4;
-    s->hmc_fold = ds->hmc_mode == 0;
+    s->hmc_tail = ds->hmc_mode == 0 || ds->hmc_mode == 3 || ds->hmc_mode == 4 || ds->hmc_mode == 5;
+    s->hmc_leap = ds->hmc_mode == 0 || ds->hmc_mode == 4 || ds->hmc_mode == 5;
+    s->hmc_fold = ds->hmc_mode == 0 || ds->hmc_mode == 5;
+    s->hmc_end = ds->hmc_mode == 0;
     for (auto &a : s->leap_occ) for (auto &b2 : a) for (int &v : b2) v = -1;
     s->moves_mode = ds->moves_mode;
     c.disable_mask = ds->disable_mask;
@@ -1111,6 +1113,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
     S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
     S_ALLOC(ch.pbar, (size_t)B * PBAR_STRIDE);
+    S_ALLOC(ch.finpart, (size_t)B * 32 * 4);
     S_ALLOC(ch.hand2, (size_t)B);
     S_ALLOC(ch.mvs, (size_t)2 * B);
     S_ALLOC(ch.DownS, (size_t)2 * B * 2);
@@ -1429,7 +1432,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         const dim3 gf((unsigned)((ntile_all / 2 + per_roles) * nbv_all));
         const unsigned long long step_base = s->leap_steps, role_base = s->leap_rsteps;
         s->leap_steps += (unsigned long long)nsteps;
-        s->leap_rsteps += (unsigned long long)(nsteps - ((fold & 2) ? 1 : 0));
+        s->leap_rsteps += (unsigned long long)(nsteps - (((fold & 2) && !(fold & 4)) ? 1 : 0));
         void *args[] = {(void *)&df, (void *)&ctx->c, (void *)&ctx->w, (void *)&c, (void *)&s->ch, (void *)&par0, (void *)&nsteps,
                         (void *)&step_base, (void *)&role_base, (void *)&fold};
         (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, 2), gf, dim3(256), args, 0, st);
@@ -1446,16 +1449,20 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             s->vt_dirty = false;
         }
         if (prof0) (void)hipEventRecord(s->prof_ev[2 * s->prof_i], st);
-        launch_leap(1, c.L + 1, 3);
+        // hmc_end: the last half kick, the accept test, adaptation and trace by the chunk roles of the same launch as well;
+        // otherwise (hmc_mode 5) k_hmc_step<2> closes the trajectory as a launch of its own
+        launch_leap(1, c.L + 1, s->hmc_end ? 7 : 3);
         if (prof0) {
             (void)hipEventRecord(s->prof_ev[2 * s->prof_i + 1], st);
             s->prof_i += 1;
             s->prof_launches = 1;
             s->prof_evals = c.L + 1;
         }
-        l.d.sp_par = c.L & 1 ? 0 : 1;       // the buffer the last role step wrote: steps alternate from buffer 1
-        l.d.chunked = 0;
-        launch_hmc(ctx, l, c, s->ch, 2, /*gather_qs=*/3);
+        if (!s->hmc_end) {
+            l.d.sp_par = c.L & 1 ? 0 : 1;       // the buffer the last role step wrote: steps alternate from buffer 1
+            l.d.chunked = 0;
+            launch_hmc(ctx, l, c, s->ch, 2, /*gather_qs=*/3);
+        }
     } else {
     l.d.chunked = 0;                       // k_se writes tile scalars only ahead of a chunked step
     launch_se<1>(ctx, l, true);

@@ -104,7 +104,7 @@ class ChainSampler:
             num_leapfrog_steps=int(num_leapfrog_steps), trace_capacity=self.cap,
             first_chain_id=int(first_chain_id), record_events=(2 if record_events == "u16" else int(self.record_events)),
             seed=int(seed) & (2 ** 64 - 1),
-            moves_mode={"paired": 0, "split": 1, "paired-nopre": 2, "paired-delta": 3, "paired-launch": 4}[moves], hmc_mode={"chunk": 0, "single": 1, "chunk-split": 2, "chunk-launch": 3, "chunk-leap": 4}[hmc],
+            moves_mode={"paired": 0, "split": 1, "paired-nopre": 2, "paired-delta": 3, "paired-launch": 4}[moves], hmc_mode={"chunk": 0, "single": 1, "chunk-split": 2, "chunk-launch": 3, "chunk-leap": 4, "chunk-stage": 5}[hmc],
             use_graph=int(bool(use_graph)), chain_groups=int(chain_groups), disable_mask=mask,
             debug_pair=int(debug_pair))
         self._s = ctypes.c_void_p()

@@ -659,18 +659,20 @@ def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,B,eps", [("uk380", 8, 1.2e-5), ("uk380", 3, 1.2e-5), ("slow_520x60", 2, 3e-5), ("micro_17x70", 8, 0.0004)])
+@pytest.mark.parametrize("name,B,eps", [("uk380", 8, 1.2e-5), ("uk380", 3, 1.2e-5), ("slow_520x60", 2, 3e-5), ("micro_17x70", 8, 0.0004),
+                                        ("micro_20x60", 8, 0.0004)])
 def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
     """The same comparison where the persistent launch has something to get wrong: the headline size (72 tile workgroups
     and 12 four-wave roles per chain, six day chunks, eight counter shards), a partial layout of 8, and M > 512 (the tiles
     also form the row scalars: the second instance of the kernels).  Three sweeps with all updates on; "chunk-leap" is the
-    persistent launch for the inner steps alone, "chunk" the one that also carries the trajectory's end points."""
+    persistent launch for the inner steps alone, "chunk-stage" the one that also carries the trajectory's first step and both
+    end-point gradients, "chunk" the whole trajectory (last half kick, accept test, adaptation and trace by the roles too)."""
     case = H.build_case(name, 43, alpha_t_sd=0.005)
     u = synth.jitter_params(case["u"], B, scale=0.002 if name == "uk380" else 0.01, seed=3, T=case["k"].T)
     ev = np.stack([case["events"]] * B)
     cfg = CFG_REF if name == "uk380" else CFG_SMALL
     out = {}
-    for mode, skew in (("chunk-split", 0), ("chunk-launch", 0), ("chunk-leap", 0), ("chunk", 0), ("chunk", 3)):
+    for mode, skew in (("chunk-split", 0), ("chunk-launch", 0), ("chunk-leap", 0), ("chunk-stage", 0), ("chunk", 0), ("chunk", 3)):
         with api[0](case["cov"], case["init"], max_chains=B) as model:
             model.set_option(debug_skew=skew)
             with api[1](model, cfg, B, seed=13, trace_capacity=3, hmc=mode) as s:
@@ -687,7 +689,7 @@ def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
     for k in ref.hmc:
         assert np.array_equal(ref.hmc[k], got.hmc[k]), k
     assert np.array_equal(ref_state[0], got_state[0]) and np.array_equal(ref_state[2], got_state[2])
-    for mode in ("chunk-leap", "chunk"):                        # the persistent launches: other orders of summation
+    for mode in ("chunk-leap", "chunk-stage", "chunk"):         # the persistent launches: other orders of summation
         got, got_state = out[(mode, 0)]
         _same_chain_up_to_rounding(ref, got)
         np.testing.assert_allclose(got_state[2], ref_state[2], rtol=1e-11, atol=0.0)
@@ -697,6 +699,54 @@ def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
     for k in base.hmc:
         assert np.array_equal(base.hmc[k], got.hmc[k]), k
     assert np.array_equal(base_state[2], got_state[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,eps,adapt", [("micro_20x60", 8, 0.0004, False), ("micro_20x60", 5, 0.0004, True), ("uk380", 8, 2e-5, False)])
+def test_trajectory_end_inside_the_launch_accepts_rejects_and_adapts_like_the_stage_kernel(api, name, B, eps, adapt):
+    """hmc="chunk" closes the trajectory inside the persistent launch -- every chunk role makes the accept test from the
+    roles' parts and applies it to its own entries, restoring the start point and rebuilding its share of the tables on
+    rejection (hmc_final_apply) -- where hmc="chunk-stage" launches k_hmc_step<2> for it (sizes at which the persistent
+    launch is used: one or six day chunks, an even number of row tiles).  With step sizes at which part of the proposals
+    is rejected, and with dual averaging and the running variance on: the same decisions, a rejected sweep leaves the
+    parameters exactly where they were, every traced quantity and the final state equal up to rounding, the adapted step
+    sizes and variances too."""
+    case = H.build_case(name, 19, alpha_t_sd=0.005)
+    u = synth.jitter_params(case["u"], B, scale=0.002 if name == "uk380" else 0.01, seed=4, T=case["k"].T)
+    ev = np.stack([case["events"]] * B)
+    cfg = CFG_REF if name == "uk380" else CFG_SMALL
+    P = case["k"].P
+    n = 10
+    seen = []
+    for scale in (1.0, 2.5):
+        out = {}
+        for mode in ("chunk-stage", "chunk"):
+            with api[0](case["cov"], case["init"], max_chains=B) as model:
+                with api[1](model, cfg, B, seed=29, trace_capacity=n, hmc=mode) as s:
+                    if not s.xcd_local():
+                        pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the fused forms are not used")
+                    s.set_state(u, ev)
+                    s.set_kernel(step_size=eps * scale)
+                    if adapt:
+                        s.set_adaptation(adapt_step_size=True, adapt_mass=True, num_adaptation_steps=n,
+                                         running_variance=(np.full(B, 5.0), np.tile(u.mean(0), (B, 1)), np.full((B, P), 0.5)))
+                    out[mode] = (s.sample(n), s.get_state(), s.get_kernel())
+                    assert not s.pair_timeouts().any()
+        ref, ref_state, ref_k = out["chunk-stage"]
+        got, got_state, got_k = out["chunk"]
+        acc = ref.hmc["is_accepted"].astype(bool)
+        assert np.array_equal(acc, got.hmc["is_accepted"].astype(bool))
+        seen.append(acc)
+        _same_chain_up_to_rounding(_head(ref, 5), _head(got, 5), rtol=1e-7)
+        # a rejected HMC update leaves the parameters of the previous draw (the event updates do not touch them)
+        for t in range(1, n):
+            for b in range(B):
+                if not got.hmc["is_accepted"][t, b]:
+                    assert np.array_equal(got.theta[t, b], got.theta[t - 1, b]), (t, b)
+        np.testing.assert_allclose(got_k[0], ref_k[0], rtol=1e-5)
+        np.testing.assert_allclose(got_k[1], ref_k[1], rtol=1e-5)
+    allacc = np.concatenate([a.ravel() for a in seen])
+    assert allacc.any() and not allacc.all(), allacc.mean()     # both branches were taken
 
 
 @pytest.mark.gpu
