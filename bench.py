@@ -280,6 +280,21 @@ def main():
     # ordinary sweeps, on the stream the kernels run on; k_se also stand-alone.
     leap_ms, leap_launches, leap_evals = sampler.time_leapfrog(min(200, max(20, K)))
     grad_ms = sampler.time_grad_kernel(200)
+    # The persistent launch also closes the trajectory (last half kick, accept test, adaptation, trace: k_hmc_step<2>'s
+    # work in the other forms), which is not gradient work: the same section with that part as a launch of its own
+    # (hmc="chunk-stage") is timed beside it, so that the gradient evaluations' own figure stays comparable over rounds.
+    leap_noend_ms = None
+    if leap_launches == 1 and world == 1:
+        with SeirModel(cov, init, max_chains=B, device=local) as mx_:      # (a context of its own: one sampler per context)
+            with ChainSampler(mx_, MCMC_CONFIG, B, seed=a.seed, first_chain_id=first_chain, trace_capacity=8,
+                              record_events=False, hmc="chunk-stage") as sx_:
+                sx_.set_state(*sampler.get_state()[:2])
+                sx_.set_kernel(*sampler.get_kernel())
+                sx_.run(10)
+                mx_.sync()
+                lm_, ll_, le_ = sx_.time_leapfrog(100)
+                if ll_ == 1 and le_ == leap_evals:
+                    leap_noend_ms = lm_
     M, T, P = cov.M, cov.T, model.P
     alg_bytes = B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
     achieved = leap_evals * alg_bytes / (leap_ms * 1e-3) / 1e9
@@ -483,8 +498,9 @@ def main():
                        "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] (uint16 counts) + kernel results per sweep",
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"kernel": (f"k_leap<TSM,NTC,2> (persistent: {leap_evals} of the sweep's 17 gradient evaluations in one launch -- the "
-                                    "whole HMC trajectory but its last half kick: per evaluation the S->E term's gradient sums of all chains "
-                                    "from register-resident cells (and its value at the two end points), then the chunk roles' leapfrog update)")
+                                    "whole HMC trajectory: per evaluation the S->E term's gradient sums of all chains "
+                                    "from register-resident cells (and its value at the two end points), then the chunk roles' leapfrog "
+                                    "update; at the end the roles' last half kick, accept test, adaptation and trace)")
                                    if leap_launches == 1 else
                                    (f"k_se_chunk (one launch per inner leapfrog step: gradient tiles + chunk roles; {leap_evals} of the sweep's 17 "
                                     "gradient evaluations)" if leap_launches == leap_evals else
@@ -497,6 +513,11 @@ def main():
                          "launches_per_section": leap_launches, "section_us": 1e3 * leap_ms,
                          "us_per_evaluation": 1e3 * leap_ms / leap_evals,
                          "mean_launch_us": 1e3 * leap_ms / leap_launches,
+                         "without_the_trajectory_end": None if leap_noend_ms is None else {
+                             "what": "the same launch with the trajectory's end as k_hmc_step<2>'s own launch (hmc='chunk-stage'): "
+                                     "the 17 gradient evaluations and 16 leapfrog steps alone",
+                             "section_us": 1e3 * leap_noend_ms, "us_per_evaluation": 1e3 * leap_noend_ms / leap_evals,
+                             "frac": leap_evals * alg_bytes / (leap_noend_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                          "note": "the persistent kernel reads its cells from HBM once per trajectory and keeps them in registers, so its "
                                  "memory traffic is far below the algorithmic bytes: what bounds it is the fp64 vector issue rate of the "
                                  "tile phase (~70 instructions per cell) and the two in-L2 hand-offs per step -- `frac` prices it "

@@ -206,17 +206,22 @@ typedef struct {
                                        the chip and wait for the rest; their waits are bounded, the sampler then fails
                                        loudly at the next read of the trace (seir_sampler_pair_timeouts), and modes 4 /
                                        hmc_mode 3 are the forms for a shared GPU */
-    int32_t hmc_mode;               /* 0: inner leapfrog steps by 64-lane chunks; all L-1 of them in ONE persistent launch
-                                       (k_leap: the gradient tiles keep their cells in registers over the steps, tiles and
-                                       chunk roles hand each other the partial sums / the next tables through the XCD's L2)
-                                       when all of a chain's workgroups share an XCD (chain b's block ids are congruent to
-                                       b mod 8; checked through XCC_ID at creation) and every workgroup of that launch fits
-                                       the chip at once; else one launch per step with the chunk roles inside the gradient
-                                       launch (k_se_chunk; needs the XCD placement only); else the chunks as their own
-                                       launch (k_hmc_chunk).  1: every step by the single-workgroup kernel; 2: chunks always
-                                       as their own launch; 3: one launch per step (k_se_chunk), never the persistent one
-                                       (2 and 3 are the cross-checks of 0: same bits).  0/2/3 against 1: same draws up to
-                                       summation order */
+    int32_t hmc_mode;               /* 0: the leapfrog steps by 64-lane chunk roles and the WHOLE trajectory in ONE
+                                       persistent launch (k_leap: the gradient tiles keep their cells in registers over the
+                                       L+1 gradient evaluations, tiles and chunk roles hand each other the partial sums / the
+                                       next tables through the XCD's L2; the roles also draw the momentum, and at the end
+                                       make the accept test -- each from the roles' parts, all alike -- restore the start
+                                       point on rejection, and do the adaptation and the trace) when all of a chain's
+                                       workgroups share an XCD (chain b's block ids are congruent to b mod 8; checked
+                                       through XCC_ID at creation) and every workgroup of that launch fits the chip at
+                                       once; else one launch per step with the chunk roles inside the gradient launch
+                                       (k_se_chunk; needs the XCD placement only) between the stage kernels
+                                       (k_hmc_step<0>, <2>); else the chunks as their own launch (k_hmc_chunk).
+                                       5: as 0 with the last half kick, accept test, adaptation and trace by
+                                       k_hmc_step<2> as a launch of its own; 4: the persistent launch for the inner steps
+                                       only; 3: one launch per step (k_se_chunk), never the persistent one; 2: chunks always
+                                       as their own launch (2 and 3: same bits; 0, 4, 5 against them: same draws up to
+                                       summation order); 1: every step by the single-workgroup kernel */
     int32_t use_graph;              /* 1: replay the sweep as a captured hipGraph (default: stream launches) */
     int32_t chain_groups;           /* chains split over this many streams (0 or 1: one stream) */
     int32_t disable_mask;           /* bit 0: HMC update, bits 1..4: S->E move, E->I move, S->E occult, E->I
