@@ -275,7 +275,7 @@ def main():
         overlapped = time.perf_counter() - t2
 
     # dominant kernel of the sweep: the gradient evaluation, 17 per sweep.  Where it fits the chip ONE persistent launch
-    # (k_leap) performs all 17 (the whole trajectory but its last half kick); otherwise the 15 inner leapfrog steps are one
+    # (k_leap) performs all 17 (the whole trajectory, its end included); otherwise the 15 inner leapfrog steps are one
     # k_se_chunk launch each and the end points plain k_se launches.  Timed in place: HIP events around that section of
     # ordinary sweeps, on the stream the kernels run on; k_se also stand-alone.
     leap_ms, leap_launches, leap_evals = sampler.time_leapfrog(min(200, max(20, K)))

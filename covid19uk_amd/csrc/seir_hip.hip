@@ -1440,9 +1440,10 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     const bool prof0 = s->prof_i >= 0 && (size_t)(2 * s->prof_i + 1) < s->prof_ev.size() && g == 0;
     const bool fold = leap_ok && s->hmc_fold;
     if (fold) {
-        // The whole trajectory but its last half kick in ONE launch: gradient at the start point, the first step (momentum
-        // draw, half kick, drift: k_hmc_step<0>'s work, by the chunk roles), the L-1 inner steps, gradient at the end point;
-        // k_hmc_step<2> then closes it (half kick, accept test, adaptation, trace).  L+1 gradient evaluations, L role steps.
+        // The whole trajectory in ONE launch: gradient at the start point, the first step (momentum draw, half kick, drift:
+        // k_hmc_step<0>'s work, by the chunk roles), the L-1 inner steps, gradient at the end point, and the end itself (half
+        // kick, accept test, adaptation, trace: by the roles as well, or -- hmc_mode 5 -- by k_hmc_step<2> as a launch of its
+        // own).  L+1 gradient evaluations, L (+1) role steps.
         if (s->vt_dirty || c.adapt_mass) {
             Dims dv = l.d;
             hipLaunchKernelGGL(k_vt, dim3(nb), dim3(WAVE), 0, st, dv, ctx->w, s->ch);

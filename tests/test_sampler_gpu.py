@@ -618,7 +618,7 @@ def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
     hmc="chunk-split" launches tiles and roles separately: the same code in the same order, every traced quantity equal
     to the last bit, with and without workgroup skew (any number of chains, in the layout of the next multiple of 8: chain
     b on XCD b mod 8; used only when the GPU places block ids congruent mod 8 on one XCD each).  hmc="chunk" runs the
-    whole trajectory but its last half kick in ONE persistent launch (k_leap: the gradient tiles keep their cells in
+    whole trajectory in ONE persistent launch (k_leap: the gradient tiles keep their cells in
     registers; tiles and chunk roles hand each other partial sums and tables through the XCD's L2; the first step draws
     the momentum as k_hmc_step<0> does in the other forms).  There the start point's energy and log-probability are
     summed in another order, so it is held to the same draws and decisions, the continuous quantities equal up to
