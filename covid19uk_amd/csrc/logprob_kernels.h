@@ -236,6 +236,79 @@ __device__ __forceinline__ void scan_rows(const Dims &d, const Consts &c, const 
     }
 }
 
+// The state part (scan_rows<0, 1>) of TWO row blocks of a chain by one workgroup, for k_eval_all's tile workgroups, which
+// scan two blocks each: the second block's events are fetched before the first block's prefix sums are formed, so that
+// their latency (first touch: HBM or the Infinity Cache, the events are read once per evaluation) runs under the first
+// block's arithmetic instead of after it.  Per block the loads, the operations and their order are scan_rows': the same
+// bits.  One batch of day chunks per row (T <= 64 SCAN_CB); the caller falls back to two calls otherwise.
+__device__ __forceinline__ void scan_rows_state2(const Dims &d, const Consts &c, const Work &w, const double *__restrict__ events,
+                                                 int bx0, int bx1, int by) {
+    extern __shared__ double lds[];                 // [SCAN_WAVES][Tp][2]
+    static_assert(SCAN_ROWS == SCAN_WAVES, "one row per wave");
+    const int b = d.b0 + by, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *mycol = lds + (size_t)wave * d.Tp * 2;
+    const int nch = d.Tp / WAVE;
+    constexpr int CB = SCAN_CB;
+    double ev_[2][3][CB];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int m = (q == 0 ? bx0 : bx1) * SCAN_ROWS + wave;
+        const double *ev = events + ((size_t)b * d.M + (m < d.M ? m : 0)) * d.T * 3;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int t = j * WAVE + lane;
+            const bool in = m < d.M && j < nch && t < d.T;
+            ev_[q][0][j] = in ? ev[(size_t)t * 3 + 0] : 0.0;
+            ev_[q][1][j] = in ? ev[(size_t)t * 3 + 1] : 0.0;
+            ev_[q][2][j] = in ? ev[(size_t)t * 3 + 2] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int bx = q == 0 ? bx0 : bx1;
+        const int m = bx * SCAN_ROWS + wave;
+        for (int i = lane; i < d.Tp * 2; i += WAVE) mycol[i] = 0.0;
+        __syncthreads();
+        if (m < d.M) {
+            const double S0 = c.init[m * 4 + 0], E0 = c.init[m * 4 + 1], I0 = c.init[m * 4 + 2];
+            const double invN = c.invN[m];
+            const size_t rowoff = ((size_t)b * d.Mp + m) * d.Tp;
+            double cse = 0.0, cei = 0.0, cir = 0.0;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                if (j >= nch) break;
+                const int t = j * WAVE + lane;
+                const bool valid = t < d.T;
+                const double kse = ev_[q][0][j], kei = ev_[q][1][j], kir = ev_[q][2][j];
+                const double ise = wave_incl_scan(kse, lane), iei = wave_incl_scan(kei, lane), iir = wave_incl_scan(kir, lane);
+                const double xse = cse + ise - kse, xei = cei + iei - kei, xir = cir + iir - kir;
+                const double S = S0 - xse, I = I0 + xei - xir;
+                w.Xn[rowoff + t] = valid ? I * invN : 0.0;
+                if (w.Xn32 != nullptr) w.Xn32[rowoff + t] = valid ? (float)(I * invN) : 0.f;
+                w.KS[rowoff + t] = valid ? make_int2((int)kse, (int)(S - kse)) : make_int2(0, 0);
+                if (valid) {
+                    mycol[t * 2 + 0] += kir;
+                    mycol[t * 2 + 1] += I - kir;
+                }
+                cse += __shfl(ise, WAVE - 1, WAVE);
+                cei += __shfl(iei, WAVE - 1, WAVE);
+                cir += __shfl(iir, WAVE - 1, WAVE);
+                (void)E0;
+            }
+        }
+        __syncthreads();
+        double *out = w.colIR + ((size_t)b * d.nrb_scan + bx) * d.Tp * 2;
+        const int n = d.Tp * 2;
+        for (int i = threadIdx.x; i < n; i += SCAN_WAVES * WAVE) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < SCAN_WAVES; ++k) a += lds[k * n + i];
+            out[i] = a;
+        }
+        __syncthreads();                                // the next block reuses the LDS
+    }
+}
+
 template <int SRC>
 __global__ __launch_bounds__(SCAN_WAVES * WAVE) void k_scan(Dims d, Consts c, Work w, const double *__restrict__ events) {
     scan_rows<SRC>(d, c, w, events, blockIdx.x, blockIdx.y);
@@ -1396,10 +1469,14 @@ void k_eval_all(Dims d, Consts c, Work w, const double *__restrict__ events, con
         const int tile_or0 = tile;
         ESTAMP(0);
         const int rbt = (d.nrb_scan + per - 1) / per;
-        for (int k = 0; k < rbt; ++k) {
-            const int rb = tile * rbt + k;
-            if (rb < d.nrb_scan) scan_rows<0, 1>(d, c, w, events, rb, chain);
-            __syncthreads();                                // the next row block reuses the scan's LDS
+        if (rbt == 2 && tile * 2 + 1 < d.nrb_scan && d.Tp <= SCAN_CB * WAVE) {
+            scan_rows_state2(d, c, w, events, tile * 2, tile * 2 + 1, chain);      // both blocks' events in flight at once
+        } else {
+            for (int k = 0; k < rbt; ++k) {
+                const int rb = tile * rbt + k;
+                if (rb < d.nrb_scan) scan_rows<0, 1>(d, c, w, events, rb, chain);
+                __syncthreads();                            // the next row block reuses the scan's LDS
+            }
         }
         ESTAMP(1);
         evc_arrive(cA);
