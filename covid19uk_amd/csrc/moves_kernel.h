@@ -32,10 +32,8 @@ namespace seir {
 #ifdef PAIR_STAMPS
 #define QSTAMP(slot_, step_, i_) do { if (threadIdx.x == 0 && (b_stamp) == 0 && (step_) < 12 && (slot_) < 27) \
     ch.leap_st[((size_t)(slot_) * 12 + (step_)) * 16 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define QWAIT(slot_, step_, i_) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QSTAMP(slot_, step_, i_); } while (0)
 #else
 #define QSTAMP(slot_, step_, i_) do {} while (0)
-#define QWAIT(slot_, step_, i_) do {} while (0)
 #endif
 
 constexpr int MVB = 512;              // threads
