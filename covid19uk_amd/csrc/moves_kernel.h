@@ -13,6 +13,8 @@
 // workgroup per chain.  It removes 40 launches per sweep but a single CU cannot carry the E->I
 // band (M x <=84 days x m cells, 60-120 us per update against 11 us spread over 48 workgroups)
 // and the fused kernel spilled; measured 1.22-1.34 ms per sweep against 1.07 ms for this split form.
+// (Round 3's k_move_pairs, at the end of this file, is the persistent form that works: 27 workgroups per chain --
+// three roles and the band -- resident for the sweep, a per-chain step barrier in place of the launch boundary.)
 #pragma once
 #include "sampler_kernels.h"
 
