@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end (HDF5-writing) single-chain measurement")
     ap.add_argument("--no-chains-scaling", action="store_true",
                     help="skip the extra (untimed-by-the-contract) runs at 32 and 64 chains on this GPU")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (BASELINE.json configs 2, 3 and 5 beside the headline: NI-11 x 16 chains, "
+                         "UK-380 x 1 chain, SYN-2048 x 8 chains with the fp32 MFMA contraction; ~30 s, most of it generating "
+                         "the 2048 x 730 synthetic epidemic on the host)")
     ap.add_argument("--cpu-baseline-sweeps", type=int, default=0, help="0 = size for ~10 s per leg")
     ap.add_argument("--spinup-seconds", type=float, default=0.7,
                     help="untimed sweeps run back to back before the timed region so that a short --steps run is "
@@ -114,6 +118,76 @@ def cpu_baseline(cov, init, events, u0, n_sweeps, seed, cores=None):
             "density_share": share,             # fraction of the time inside the C density (the rest: NumPy proposal logic)
             "sample": f"{n} sweeps of 1 chain, oracle/mcmc_oracle.py + oracle/seir_oracle.c (OpenMP, "
                       f"{cores} threads), {ch.n_evals} full log-prob evaluations, same workload"}
+
+
+def alg_bytes_per_eval(M, T, P, B):
+    """algorithmic bytes of one gradient evaluation of B chains (fp64 events + vectors per chain, Cstar once)."""
+    return B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
+
+
+def aux_config(label, workload, B, local, seed, steps, warm, eps, f32=False):
+    """One of BASELINE.json's other configurations on this GPU, beside the headline: `steps` timed sweeps of B chains after
+    `warm` untimed ones (HIP events on the context stream, inputs resident, draws recorded to the burst buffer), the sweep's
+    dominant kernel -- the leapfrog section, timed in place -- priced like the headline's, and for the fp32 configuration the
+    mobility contraction against the fp32 MFMA peak.  Fixed step size, no adaptation: a throughput figure."""
+    import torch
+    from covid19uk_amd import synth
+    from covid19uk_amd.sampler import ChainSampler
+    from covid19uk_amd.seir import SeirModel
+    t_start = time.perf_counter()
+    cov = synth.make_covariates(workload, seed)
+    events, init, truth = synth.simulate_epidemic(cov, seed)
+    u = synth.jitter_params(synth.unconstrain(synth.pack_params(truth, cov.M, cov.T)), B, scale=0.002, seed=7, T=cov.T)
+    ev = np.stack([events] * B)
+    M, T = cov.M, cov.T
+    out = {"config": label, "workload": f"{workload}: M={M} x T={T}", "chains_per_gpu": B, "steps": steps, "warmup": warm}
+    with SeirModel(cov, init, max_chains=B, device=local) as model:
+        P = model.P
+        if f32:
+            model.set_option(gemm_f32=True)
+        with ChainSampler(model, MCMC_CONFIG, B, seed=seed, trace_capacity=steps, record_events="u16") as s:
+            s.set_state(u, ev)
+            s.set_kernel(step_size=eps)
+            s.run(warm)
+            model.sync()
+            s.reset_trace()
+            model.timer_start()
+            s.run(steps)
+            ms = model.timer_stop()
+            tr = s.read_trace(steps, events=False)
+            lm, ll, le = s.time_leapfrog(min(20, steps))
+            alg = alg_bytes_per_eval(M, T, P, B)
+            out.update({
+                "value": B * steps / (ms * 1e-3), "unit": "posterior samples/sec", "ms_per_step": ms / steps,
+                "dtype": "f64 (mobility contraction: fp32 MFMA)" if f32 else "f64",
+                "hmc_acceptance": float(tr.hmc["is_accepted"].mean()),
+                "all_log_probs_finite": bool(np.isfinite(tr.hmc["target_log_prob"]).all()),
+                "launch_form": list(s.launch_form()), "recoveries": len(s.recoveries),
+                "dominant_kernel": {
+                    "kernel": ("k_leap (persistent: the whole HMC trajectory)" if ll == 1 else
+                               "k_se_chunk (one launch per inner leapfrog step)" if ll == le else "k_se + k_hmc_chunk"),
+                    "launches_per_sweep": ll, "gradient_evaluations": le, "section_us": 1e3 * lm,
+                    "share_of_sweep": lm / (ms / steps), "bound": "hbm",
+                    "achieved": le * alg / (lm * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": le * alg / (lm * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "algorithmic_bytes_per_evaluation": alg}})
+        if f32:
+            # BASELINE config 5 names the contraction F = Cstar . X (model_spec.py:258-263) on the fp32 matrix cores: once
+            # per burst in the sampler (the event updates keep F current by rank-1 bands), every call in the stateless path
+            dev = torch.device("cuda", local)
+            ut, evt = torch.tensor(u, device=dev), torch.tensor(ev, device=dev)
+            lp = torch.empty(B, dtype=torch.float64, device=dev)
+            gr = torch.empty(B, P, dtype=torch.float64, device=dev)
+            model.log_prob_dev(ut, evt, lp, gr)
+            model.sync()
+            ms_g = model.time_kernel("gemm", B, 10)
+            flops = 2.0 * M * M * T * B
+            out["contraction"] = {"kernel": "k_gemm_f32 (v_mfma_f32_32x32x2_f32, 128 x 128 tiles)", "bound": "mfma",
+                                  "mean_launch_us": 1e3 * ms_g, "achieved": flops / (ms_g * 1e-3) / 1e12,
+                                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": flops / (ms_g * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    out["wall_s_including_setup"] = time.perf_counter() - t_start
+    return out
 
 
 def self_launch(n):
@@ -296,7 +370,7 @@ def main():
                 if ll_ == 1 and le_ == leap_evals:
                     leap_noend_ms = lm_
     M, T, P = cov.M, cov.T, model.P
-    alg_bytes = B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
+    alg_bytes = alg_bytes_per_eval(M, T, P, B)
     achieved = leap_evals * alg_bytes / (leap_ms * 1e-3) / 1e9
     achieved_k_se = alg_bytes / (grad_ms * 1e-3) / 1e9
     # what this kernel itself moves: int32 k_se, S, I + fp64 F per padded cell (20 B), the per-row /
@@ -426,7 +500,7 @@ def main():
         sampler.close()
         model.close()
         scaling = {}
-        for Bx in (1, 32, 64):                            # 1: BASELINE config 2 (a single chain on one GPU)
+        for Bx in (16, 32, 64):                           # (a single chain on one GPU -- BASELINE config 3 -- is in `configs`)
             ux = synth.jitter_params(u_true, Bx, scale=0.002, seed=7, T=cov.T)
             mx = SeirModel(cov, init, max_chains=Bx, device=local)
             sx = ChainSampler(mx, MCMC_CONFIG, Bx, seed=a.seed, first_chain_id=0, trace_capacity=40,
@@ -482,6 +556,27 @@ def main():
         s1.close()
         m1.close()
 
+    # BASELINE.json's other configurations on the driver's line (N=1, default workload only): each a short run of its own
+    # sampler after the headline's has been closed.  Stated budget: ~30 s in all, two thirds of it the host-side
+    # simulation of the 2048 x 730 synthetic epidemic.
+    configs = None
+    if world == 1 and rank == 0 and a.workload == "uk380" and not a.no_configs:
+        if scaling is None:
+            sampler.close()
+            model.close()
+            scaling = {}                                   # (closed: nothing below touches them)
+        configs, t_cfg = [], time.perf_counter()
+        for label, wl, Bc, st_, wm_, eps_, f32_ in (
+                ("BASELINE config 2: 11-LAD NI, 16 chains on one GPU", "ni11", 16, 200, 50, 0.002, False),
+                ("BASELINE config 3: 380-LAD UK x 365 days, single chain", "uk380", 1, 100, 30, float(np.mean(pooled)), False),
+                ("BASELINE config 5: synthetic 2048 x 730, 8 chains per GPU, fp32 MFMA mobility contraction", "syn2048", 8, 12, 3,
+                 2e-6, True)):
+            try:
+                configs.append(aux_config(label, wl, Bc, local, a.seed, st_, wm_, eps_, f32_))
+            except Exception as e:                          # an extra, never the reason a bench line is missing
+                configs.append({"config": label, "error": repr(e)})
+        configs.append({"budget_note": "stated budget ~30 s", "wall_s": time.perf_counter() - t_cfg})
+
     if rank == 0:
         out = {
             "metric": {"uk380": "posterior samples/sec, 380-LAD UK SEIR", "ni11": "posterior samples/sec, 11-LAD NI SEIR",
@@ -507,6 +602,13 @@ def main():
                                     f"k_se + k_hmc_chunk (two launches per inner leapfrog step; {leap_evals} of the sweep's 17 gradient evaluations)"),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         # `frac` above is the contract's figure: ALGORITHMIC bytes / duration / peak.  It is not a utilisation
+                         # for the persistent launch (cells are read once per trajectory and kept in registers), so the two
+                         # readings are also given under names that say what they are:
+                         "frac_algorithmic_bytes": achieved / HBM_PEAK_GBPS,
+                         "frac_measured_traffic": (traffic / (leap_ms * 1e-3 / leap_launches) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "limited_by": ("fp64 vector issue of the tile phase + two in-L2 hand-offs per leapfrog step (latency), not bandwidth"
+                                        if leap_launches == 1 else "HBM / fabric streaming of the planes, then role latency"),
                          "frac_uses": "algorithmic bytes of SURVEY.md 8d (fp64 events + vectors per chain, Cstar once) x the gradient "
                                       "evaluations the timed section performs / its duration (HIP events around it in ordinary sweeps)",
                          "algorithmic_bytes_per_evaluation": alg_bytes, "evaluations_per_section": leap_evals,
@@ -546,6 +648,8 @@ def main():
             out["cli_samples_per_sec"] = cli
         if scaling:
             out["chains_per_gpu_scaling"] = scaling
+        if configs:
+            out["configs"] = configs
         if contraction:
             # at SYN-2048 the line's `roofline` is the matrix-core contraction BASELINE config 5 names; the sweep's own
             # dominant kernel (HBM-bound, as at UK-380) stays alongside

@@ -43,7 +43,7 @@ class SeirSamplerDesc(ctypes.Structure):
         # ABI v2: launch form and test hooks, all-zero = defaults
         ("moves_mode", ctypes.c_int32), ("hmc_mode", ctypes.c_int32), ("use_graph", ctypes.c_int32),
         ("chain_groups", ctypes.c_int32), ("disable_mask", ctypes.c_int32), ("debug_pair", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 2),
+        ("leap_rows", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
     ]
 
 
@@ -60,14 +60,22 @@ class SeirSimDesc(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 2               # SEIR_ABI_VERSION
+ABI_VERSION = 3               # SEIR_ABI_VERSION
 OPT_DEBUG_SKEW, OPT_XCD_AFFINITY, OPT_GEMM_F32, OPT_EVAL_FORM = 0, 1, 2, 3
 MMAX = 4                      # SEIR_MMAX
 MOVE_TRACE = 2 + 4 * MMAX     # SEIR_MOVE_TRACE
 
 
 class SeirError(RuntimeError):
-    pass
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
+
+
+class HandoffTimeout(SeirError):
+    """A wait inside one of the persistent launches timed out (SEIR_ERR_STATE from a read of the trace): its
+    workgroups were not all resident -- something else holds part of the GPU.  `ChainSampler` recovers from it by
+    itself (snapshot, restore, per-step launch forms)."""
 
 
 # name -> (restype, argtypes); every symbol include/seir_hip.h declares
@@ -129,6 +137,12 @@ _SIGNATURES = {
                                                   ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "seir_sampler_pair_timeouts": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
     "seir_sampler_xcd_local": (ctypes.c_int, [ctypes.c_void_p]),
+    "seir_sampler_snapshot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "seir_sampler_restore": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "seir_sampler_debug_fail_handoff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "seir_sampler_set_launch_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]),
+    "seir_sampler_launch_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
+                                                ctypes.POINTER(ctypes.c_int32)]),
 }
 
 _lib = None
@@ -168,4 +182,6 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().seir_last_error()
-        raise SeirError(f"libseirhip call failed ({rc}): {msg.decode() if msg else '?'}")
+        text = msg.decode() if msg else "?"
+        cls = HandoffTimeout if (rc == -3 and "hand-off(s) timed out" in text) else SeirError
+        raise cls(f"libseirhip call failed ({rc}): {text}", rc)

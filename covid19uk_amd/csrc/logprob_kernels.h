@@ -746,18 +746,27 @@ __device__ __forceinline__ void se_cells(double ea_t, const double (&eb)[NR], co
 
 // L = log(1 - e^-r) of cells whose rates se_cells<NR, false> has formed: the end points of a trajectory inside k_leap
 // (a cold block there; the same series and the same fallback as se_cells)
+// (the arguments outside the series' range -- a daily hazard above 1/8: rare -- go through libm OUT OF LINE: inlined, exp and
+// log cost ~40 registers in the middle of k_leap's step loop, whose tile workgroups hold their cells in registers across
+// it; the allocator then parked loop-invariant cell registers in scratch and reloaded them in every step)
+__device__ __attribute__((noinline)) double l1me_L_slow(double r) {
+    const double e = exp(-r), om = 1.0 - e;           // l1me_inv's branch, operation for operation
+    return log(om);
+}
 template <int NR>
 __device__ __forceinline__ void se_cells_L(const double (&rr)[NR], const double2 *ltab, const SeK &sk, double (&L)[NR]) {
+    bool odd = false;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const double x = rr[r];
-        if (x >= L1ME_SERIES_MIN && x <= L1ME_SERIES_MAX) {
-            const double x2 = x * x;
-            L[r] = fast_log_k(x, ltab, sk) + x * (sk.mhalf + x * (sk.l1 - x2 * (sk.l2 - x2 * (sk.l3 - x2 * sk.l4))));
-        } else {
-            double inv_;
-            l1me_inv(x, L[r], inv_, ltab);
-        }
+        const double x2 = x * x;
+        L[r] = fast_log_k(x, ltab, sk) + x * (sk.mhalf + x * (sk.l1 - x2 * (sk.l2 - x2 * (sk.l3 - x2 * sk.l4))));
+        odd = odd || !(x >= L1ME_SERIES_MIN && x <= L1ME_SERIES_MAX);
+    }
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (!(rr[r] >= L1ME_SERIES_MIN && rr[r] <= L1ME_SERIES_MAX)) L[r] = l1me_L_slow(rr[r]);
     }
 }
 

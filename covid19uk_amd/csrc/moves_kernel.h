@@ -855,7 +855,13 @@ __device__ __forceinline__ void wait_token(const unsigned *p_, unsigned token, u
     int spins = 0;
     while (ld_l2(p_) != token) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) { *late += 1; break; }       // ~0.1 s: never seen; counted, no hang
+        ++spins;
+        // once ANY wait of the chain has timed out (its workgroups cannot all have been placed: something else holds part of
+        // the chip) every later wait of the chain gives up at its first look at the counter, every 256 polls, so that a burst
+        // that cannot complete drains in about a second instead of a second per wait (as leap_wait); the host finds the
+        // counter at the next read of the trace, fails loudly and can restore the last snapshot (seir_sampler_restore)
+        if ((spins & 255) == 0 && ld_l2(late) != 0u) break;
+        if (spins > (1 << 22)) { __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // counted, no hang
     }
 }
 // SOLO (k_move_pairs): the workgroup has its CU to itself and its L1 was emptied when the step began, so what it loads of
@@ -1559,9 +1565,12 @@ __device__ __forceinline__ void pair_chain_barrier(const Chains &ch, int b, unsi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (old + 1u != target) {
             int spins = 0;
+            unsigned *late = ch.late + ch.late_fatal + b;
             while ((int)(ld_l2(cnt) - target) < 0) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { ch.late[ch.late_fatal + b] += 1; break; }     // ~0.1 s: counted, no hang
+                ++spins;
+                if ((spins & 255) == 0 && ld_l2(late) != 0u) break;                          // (see wait_token)
+                if (spins > (1 << 22)) { __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // counted, no hang
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1635,8 +1635,10 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
         if (ntile >= 32) __builtin_amdgcn_s_sleep(TAIL_BACKOFF);
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) {                 // ~0.1 s: never seen; counted like k_move_pair's time-outs, no hang
-                if (threadIdx.x == 0) ch.late[ch.late_fatal + b] += 1;
+            ++spins;
+            if ((spins & 255) == 0 && __hip_atomic_load(ch.late + ch.late_fatal + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // see leap_wait
+            if (spins > (1 << 22)) {                   // never seen; counted like k_move_pair's time-outs, no hang
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(ch.late + ch.late_fatal + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
@@ -1732,40 +1734,46 @@ __device__ __forceinline__ void leap_wait(const unsigned long long *flag, unsign
 // whatever NST); what grows with NST is the work per wave and what shrinks is everything paid per workgroup: arrivals on
 // the chain's counters, polls, barriers, reductions' fixed parts, and the number of waves the literals of the polynomials
 // are materialised for.
-template <int TSM, int NST>
+// RW: rows per wave (a gradient tile is TM = 4 RW rows x 64 days).  RW = 4 is se_tile's own shape (its partial sums to the bit);
+// RW = 6 with NST = 1 gives 24-row workgroups -- at UK-380 (Mp = 384) 96 tile workgroups per chain, exactly three per CU of the
+// chain's XCD and 18 cells per lane on every SIMD, where the 32-row workgroups (72 per chain) put three on eight CUs and two on
+// the other twenty-four: the step waited for the SIMDs that carry 24.  The row sums then take another order of additions
+// (eight lanes per row, eight entries each): the same draws up to rounding, like every other difference between the forms.
+template <int TSM, int NST, int RW = SE_RW>
 __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s, const Chains &ch,
                                           int bx, int byg, int bz, int par0, int nsteps, unsigned long long step_base,
                                           unsigned long long role_base, int fold) {
     // fold (the trajectory's end points inside this launch): bit 0 = the first of the nsteps evaluations is the gradient at the
     // START point (the roles' first step draws the momentum: k_hmc_step<0>'s work), bit 1 = the last one is the gradient at the END
     // point, for k_hmc_step<2> (no role follows it).  At those two the S->E term's value is summed as well (Lpart0 / Lpart).
+    constexpr int TM = 4 * RW;
     __shared__ double colbuf[NST][4][WAVE];
     __shared__ double psibuf[NST][4][WAVE], llbuf[NST][4][WAVE];
-    __shared__ double rowbuf[NST][4 * SE_RW * SE_RS];
+    __shared__ double rowbuf[NST][4 * RW * SE_RS];
     __shared__ double rlbuf[TSM == 2 ? NST : 1][4][WAVE], rsbuf[TSM == 2 ? NST : 1][4][WAVE];
     __shared__ double2 ltab[LDSTAB_N];
     // the step's tables, fetched past the L1 by one wave each and handed to the others through LDS: exp(a_t) of the 64 days
     // (wave 0) | exp(b_m)/N_m of the rows (wave 1) | the rows' spatial effects (TSM 2, wave 2) | psi (wave 3).  With every
     // wave loading its own operands the 576 waves of a chain all asked the L2 for the same few lines at the same moment
-    __shared__ double tabbuf[WAVE + 2 * NST * SE_TM + 8];
-    constexpr int TB_EB = WAVE, TB_SP = WAVE + NST * SE_TM, TB_PSI = WAVE + 2 * NST * SE_TM;
-    static_assert(NST * SE_TM <= WAVE, "one wave fetches the rows' table entries");
+    __shared__ double tabbuf[WAVE + 2 * NST * TM + 8];
+    constexpr int TB_EB = WAVE, TB_SP = WAVE + NST * TM, TB_PSI = WAVE + 2 * NST * TM;
+    static_assert(NST * TM <= WAVE, "one wave fetches the rows' table entries");
     auto LDP = [](const double *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     debug_skew(d);
     const int b = d.b0 + bz, wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
     const int t0 = bx * WAVE + lane0;
-    const int mg = byg * NST * SE_TM;                            // first row of the workgroup's tiles
+    const int mg = byg * NST * TM;                            // first row of the workgroup's tiles
     const int ntile = d.ntc * d.nmt, nwg = ntile / NST;          // gradient tiles / tile workgroups of a chain
     if (threadIdx.x < LOGTAB_N) ltab[threadIdx.x] = c.logtab[threadIdx.x];
     // ---- the step-invariant operands, once: the tiles' cells in registers, the per-day and per-row constants
     const double Wt = c.W[t0];
-    double F[NST][SE_RW];
-    int Ii[NST][SE_RW], ki[NST][SE_RW], si[NST][SE_RW];
+    double F[NST][RW];
+    int Ii[NST][RW], ki[NST][RW], si[NST][RW];
 #pragma unroll
     for (int st = 0; st < NST; ++st)
 #pragma unroll
-        for (int r = 0; r < SE_RW; ++r) {
-            const size_t q = ((size_t)b * d.Mp + mg + st * SE_TM + wave * SE_RW + r) * d.Tp + t0;
+        for (int r = 0; r < RW; ++r) {
+            const size_t q = ((size_t)b * d.Mp + mg + st * TM + wave * RW + r) * d.Tp + t0;
             F[st][r] = w.F[q];
             ki[st][r] = w.K[0][q];
             Ii[st][r] = w.St[2][q];
@@ -1773,11 +1781,11 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
         }
     constexpr bool ts_rows = TSM == 2;
     const int wu = __builtin_amdgcn_readfirstlane(wave);
-    double ts_l[NST][SE_RW];
+    double ts_l[NST][RW];
 #pragma unroll
     for (int st = 0; st < NST; ++st)
 #pragma unroll
-        for (int r = 0; r < SE_RW; ++r) ts_l[st][r] = ts_rows ? c.la[mg + st * SE_TM + wu * SE_RW + r] : 0.0;
+        for (int r = 0; r < RW; ++r) ts_l[st][r] = ts_rows ? c.la[mg + st * TM + wu * RW + r] : 0.0;
     const double ts_vt = w.Vt[(size_t)b * d.Tp + t0];
     // this workgroup's shard of the chain's counters: workgroups g, g + nsh, g + 2 nsh ... count in together
     const int tix = byg * d.ntc + bx, nsh = min(LEAP_NSH, nwg), shard = tix % nsh;
@@ -1785,6 +1793,73 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
     const unsigned long long *flag2 = LEAP_FLAG2(b, shard);
     unsigned long long *cnt1 = LEAP_CNT1(b, shard), *flag1 = LEAP_FLAG1(b, shard);
     __syncthreads();                                             // ltab
+    // The S->E term's VALUE at the trajectory's two end points (fold bits 0 and 1), from the tables in `tabbuf`: NOT part of
+    // the step loop.  Inside it -- a cold block behind the gradient, taken twice per launch -- its registers (the table
+    // logarithm of every cell, libm for the rare rate outside the series' range) came on top of the cells the workgroup
+    // keeps in registers across the loop, and the allocator parked loop-invariant cell registers in scratch and reloaded
+    // them in EVERY step (20 B per lane in the 32-row form, 60-190 B in the 24-row form at 128 registers).  As passes of
+    // their own before and after the loop they cost the hot path nothing.  Same operations on the same operands as
+    // se_cells / se_cells_L, the sums in the order the in-loop block formed them: the same bits.
+    auto ll_pass = [&](double *Lp) {
+        SeK sk;
+        sk.load();
+        const double psiW = tabbuf[TB_PSI] * Wt, ea_t = tabbuf[lane0];
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            double ll = 0.0;
+            constexpr int CBL = RW == 6 ? 3 : RW;
+#pragma unroll
+            for (int r0 = 0; r0 < RW; r0 += CBL) {
+                double rr[CBL], L[CBL];
+#pragma unroll
+                for (int r = 0; r < CBL; ++r) {
+                    const double ee = ea_t * tabbuf[TB_EB + st * TM + wave * RW + r0 + r];
+                    const double lam0 = ee * ((double)Ii[st][r0 + r] + psiW * F[st][r0 + r]);
+                    rr[r] = (lam0 + d.rate_floor) * d.dt;
+                }
+                se_cells_L<CBL>(rr, ltab, sk, L);
+#pragma unroll
+                for (int r = 0; r < CBL; ++r) {
+                    const double kse = (double)ki[st][r0 + r], snk = (double)(si[st][r0 + r] - ki[st][r0 + r]);
+                    ll += (kse != 0.0 ? kse * L[r] : 0.0) - snk * rr[r];
+                }
+            }
+            llbuf[st][wave][lane0] = ll;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)(byg * NST + st) * d.ntc + bx;
+                const double v = wave_sum((llbuf[st][0][lane0] + llbuf[st][1][lane0]) + (llbuf[st][2][lane0] + llbuf[st][3][lane0]));
+                if (lane0 == 0) Lp[tile] = v;
+            }
+        }
+    };
+    // the step's tables, one wave each (`first`: the start point of a folded trajectory -- its spatial effects are q0's own)
+    auto fetch_tables = [&](int lane, int t, int par, bool first) {
+        if (wu == 0) {
+            tabbuf[lane] = LDP(w.ea + (size_t)b * d.Tp + t);
+        } else if (wu == 1) {
+            if (lane < NST * TM) tabbuf[TB_EB + lane] = LDP(w.eb + (size_t)b * d.Mp + mg + lane);
+        } else if (wu == 2) {
+            if (ts_rows && lane < NST * TM) {
+                const int row = mg + lane;
+                double v_;
+                if (first) v_ = row < d.M ? LDP(ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1 + row) : 0.0;
+                else v_ = LDP(w.sp + ((size_t)b * 2 + par) * d.Mp + row);
+                tabbuf[TB_SP + lane] = v_;
+            }
+        } else {
+            if (lane == 0) tabbuf[TB_PSI] = LDP(w.scal + (size_t)b * NSCAL + SC_PSI);
+        }
+    };
+    if (fold & 1) {                                              // the start point's value: before the first step
+        fetch_tables(lane0, t0, par0, true);
+        __syncthreads();
+        ll_pass(w.Lpart0);
+        __syncthreads();                                         // (tabbuf and llbuf are written again by the first step)
+    }
     for (int it = 0; it < nsteps; ++it) {
         const int par = par0 ^ (it & 1);
         // (opaque copies made inside the loop: the per-lane addresses of the step are then not loop-invariant for the
@@ -1802,22 +1877,7 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             if (threadIdx.x == 0) { LSTAMP_MIN(0); LSTAMP_MAX(1); }
             LPROBE(0);
             LALL(0);
-            if (wu == 0) {
-                tabbuf[lane] = LDP(w.ea + (size_t)b * d.Tp + t);
-            } else if (wu == 1) {
-                if (lane < NST * SE_TM) tabbuf[TB_EB + lane] = LDP(w.eb + (size_t)b * d.Mp + mg + lane);
-            } else if (wu == 2) {
-                // (the first evaluation of a folded trajectory: the start point's spatial effects are q's own)
-                if (ts_rows && lane < NST * SE_TM) {
-                    const int row = mg + lane;
-                    double v_;
-                    if ((fold & 1) && it == 0) v_ = row < d.M ? LDP(ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1 + row) : 0.0;
-                    else v_ = LDP(w.sp + ((size_t)b * 2 + par) * d.Mp + row);
-                    tabbuf[TB_SP + lane] = v_;
-                }
-            } else {
-                if (lane == 0) tabbuf[TB_PSI] = LDP(w.scal + (size_t)b * NSCAL + SC_PSI);
-            }
+            fetch_tables(lane, t, par, (fold & 1) && it == 0);
         }
         SeK sk;
         sk.load();                                               // the series' literals as scalars (device_math.h), per step
@@ -1826,59 +1886,74 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
         const double psi = tabbuf[TB_PSI];
         const double ea_t = tabbuf[lane];
         const double psiW = psi * Wt;
-        const bool with_ll = ((fold & 1) && it == 0) || ((fold & 2) && it == nsteps - 1);       // uniform
+        constexpr bool with_ll = false;                          // (the term's value: ll_pass, outside the loop)
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-            double eb[SE_RW], ts_s[SE_RW];
+            double eb[RW], ts_s[RW];
 #pragma unroll
-            for (int r = 0; r < SE_RW; ++r) {
-                eb[r] = tabbuf[TB_EB + st * SE_TM + wave * SE_RW + r];
-                ts_s[r] = ts_rows ? tabbuf[TB_SP + st * SE_TM + wave * SE_RW + r] : 0.0;
+            for (int r = 0; r < RW; ++r) {
+                eb[r] = tabbuf[TB_EB + st * TM + wave * RW + r];
+                ts_s[r] = ts_rows ? tabbuf[TB_SP + st * TM + wave * RW + r] : 0.0;
             }
-            double *myrow = rowbuf[st] + wave * SE_RW * SE_RS;
+            double *myrow = rowbuf[st] + wave * RW * SE_RS;
             double gpsi = 0.0, colacc = 0.0, rlacc = 0.0, rsacc = 0.0, ll = 0.0;
-            // the four cells side by side (se_cells: se_tile's own evaluation).  Only the GRADIENT of the S->E term drives a
+            // the cells side by side (se_cells: se_tile's own evaluation).  Only the GRADIENT of the S->E term drives a
             // leapfrog step: the term's value (and with it log(1 - e^-r), a third of a cell's instructions) is needed at the
-            // trajectory's end points alone (with_ll) -- everywhere else the series' logarithm is dead code on the taken path
-            double Id[SE_RW], ee[SE_RW], lam0[SE_RW], rr[SE_RW], L[SE_RW], inv[SE_RW];
+            // trajectory's end points alone (with_ll) -- everywhere else the series' logarithm is dead code on the taken path.
+            // CB cells in flight at a time: all four of a 16-row tile's; of six rows per wave two batches of three, which is
+            // what fits the 128 registers of four waves per SIMD (six interleaved chains of the series: 171) -- with four
+            // waves on a SIMD three independent chains per wave already cover the fp64 latency
+            #ifndef LEAP_CB6
+#define LEAP_CB6 3
+#endif
+            constexpr int CB = RW == 6 ? LEAP_CB6 : RW;
 #pragma unroll
-            for (int r = 0; r < SE_RW; ++r) Id[r] = (double)Ii[st][r];
-            se_cells<SE_RW, false>(ea_t, eb, Id, psiW, F[st], d.rate_floor, d.dt, ltab, sk, ee, lam0, rr, L, inv);
+            for (int r0 = 0; r0 < RW; r0 += CB) {
+                double Id[CB], ebb[CB], Fb[CB], ee[CB], lam0[CB], rr[CB], L[CB], inv[CB];
 #pragma unroll
-            for (int r = 0; r < SE_RW; ++r) {
-                const double kse = (double)ki[st][r], snk = (double)(si[st][r] - ki[st][r]);
-                const bool has = kse != 0.0;
-                const double gl = d.dt * ((has ? kse * inv[r] : 0.0) - snk);
-                const double ge = gl * lam0[r];
-                myrow[r * SE_RS + lane] = ge;
-                colacc += ge;
-                if (ts_rows) {
-                    rlacc = fma(ge, ts_l[st][r], rlacc);
-                    rsacc = fma(ge, ts_s[r], rsacc);
+                for (int r = 0; r < CB; ++r) { Id[r] = (double)Ii[st][r0 + r]; ebb[r] = eb[r0 + r]; Fb[r] = F[st][r0 + r]; }
+                se_cells<CB, false>(ea_t, ebb, Id, psiW, Fb, d.rate_floor, d.dt, ltab, sk, ee, lam0, rr, L, inv);
+#pragma unroll
+                for (int r = 0; r < CB; ++r) {
+                    const double kse = (double)ki[st][r0 + r], snk = (double)(si[st][r0 + r] - ki[st][r0 + r]);
+                    const bool has = kse != 0.0;
+                    const double gl = d.dt * ((has ? kse * inv[r] : 0.0) - snk);
+                    const double ge = gl * lam0[r];
+                    myrow[(r0 + r) * SE_RS + lane] = ge;
+                    colacc += ge;
+                    if (ts_rows) {
+                        rlacc = fma(ge, ts_l[st][r0 + r], rlacc);
+                        rsacc = fma(ge, ts_s[r0 + r], rsacc);
+                    }
+                    gpsi += gl * ee[r] * Wt * Fb[r];
                 }
-                gpsi += gl * ee[r] * Wt * F[st][r];
+                if (with_ll) {                                   // the trajectory's end points only: a cold block, behind the hot one
+                    se_cells_L<CB>(rr, ltab, sk, L);
+#pragma unroll
+                    for (int r = 0; r < CB; ++r) {
+                        const double kse = (double)ki[st][r0 + r], snk = (double)(si[st][r0 + r] - ki[st][r0 + r]);
+                        ll += (kse != 0.0 ? kse * L[r] : 0.0) - snk * rr[r];
+                    }
+                }
+                if (CB != RW) __builtin_amdgcn_sched_barrier(0);  // one batch after the other: interleaved they need the registers of RW
             }
             psibuf[st][wave][lane] = gpsi;
-            if (with_ll) {                                       // the trajectory's end points only: a cold block, behind the hot one
-                se_cells_L<SE_RW>(rr, ltab, sk, L);
-#pragma unroll
-                for (int r = 0; r < SE_RW; ++r) {
-                    const double kse = (double)ki[st][r], snk = (double)(si[st][r] - ki[st][r]);
-                    ll += (kse != 0.0 ? kse * L[r] : 0.0) - snk * rr[r];
-                }
-                llbuf[st][wave][lane] = ll;
-            }
+            if (with_ll) llbuf[st][wave][lane] = ll;
             colbuf[st][wave][lane] = colacc;
             {
-                constexpr int LPR = WAVE / SE_RW;
+                // the row sums through one LDS transpose: LPR lanes per row, each adds WAVE / LPR entries, then shuffles
+                // (RW = 4: se_tile's sixteen lanes per row; otherwise eight -- 8 RW <= 64 lanes at work)
+                constexpr int LPR = RW == 4 ? 16 : 8, NE = WAVE / LPR;
+                static_assert(RW * LPR <= WAVE, "rows per wave");
                 const int rr_ = lane / LPR, ss = lane % LPR;
-                const double *src = myrow + rr_ * SE_RS + ss;
+                const bool rrow = rr_ < RW;
+                const double *src = myrow + (rrow ? rr_ : 0) * SE_RS + ss;
                 double v = 0.0;
 #pragma unroll
-                for (int j = 0; j < SE_RW; j += 2) v += src[j * LPR] + src[(j + 1) * LPR];
+                for (int j = 0; j < NE; j += 2) v += src[j * LPR] + src[(j + 1) * LPR];
 #pragma unroll
                 for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, WAVE);
-                if (ss == 0) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + mg + st * SE_TM + wave * SE_RW + rr_] = v;
+                if (ss == 0 && rrow) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + mg + st * TM + wave * RW + rr_] = v;
                 if (ts_rows) { rlbuf[st][wave][lane] = rlacc; rsbuf[st][wave][lane] = rsacc; }
             }
         }
@@ -1919,6 +1994,10 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             }
         }
         LPROBE(4);                                               // wave 0's reductions issued
+        if ((fold & 2) && it == nsteps - 1) {                    // the end point: its value as well, before the tile counts in
+            __syncthreads();                                     // (llbuf: nobody reads the step's LDS sums any more)
+            ll_pass(w.Lpart);
+        }
         __syncthreads();                                         // vmcnt(0): this step's partial sums are in the XCD's L2
         LPROBE(5);                                               // stores acknowledged
         if (threadIdx.x == 0) {
@@ -1940,20 +2019,32 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
     }
 }
 
-constexpr int leap_waves_per_simd(int nst) { return nst == 1 ? 5 : 3; }
-template <int TSM, int NTC, int NST>
-__global__ __launch_bounds__(256, NTC == 12 ? (leap_waves_per_simd(NST) < 3 ? leap_waves_per_simd(NST) : 3) : leap_waves_per_simd(NST))
+// waves per SIMD the instance is compiled for: the launch needs every workgroup resident, so the register budget follows from
+// how many workgroups a CU must hold (RW = 6, one 24-row tile per workgroup: three tile workgroups per CU and the roles beside
+// them -- four waves per SIMD, 128 VGPRs)
+#ifndef LEAP_RW6_WAVES
+#define LEAP_RW6_WAVES 4
+#endif
+constexpr int leap_waves_per_simd(int nst, int rw = SE_RW) { return rw == 6 ? LEAP_RW6_WAVES : nst == 1 ? 5 : 3; }
+template <int TSM, int NTC, int NST, int RW = SE_RW>
+__global__ __launch_bounds__(256, (NTC == 12 && RW == SE_RW) ? (leap_waves_per_simd(NST) < 3 ? leap_waves_per_simd(NST) : 3) : leap_waves_per_simd(NST, RW))
 void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nsteps, unsigned long long step_base,
             unsigned long long role_base, int fold) {
+    // (d.nmt: row tiles of THIS launch's shape, Mp / (4 RW) -- the host passes it; the roles read the partial sums by it)
     const int nwg = d.ntc * d.nmt / NST, n_tiles = nwg * d.aff_nb;   // tile workgroups per chain: NST gradient tiles each
     const int nroles = d.ntc + d.Mp / WAVE;
     if ((int)blockIdx.x < n_tiles) {
         int bz, tile;
         xcd_affine(blockIdx.x, nwg, d.aff_nb, bz, tile);
         if (d.nlive > 0 && bz >= d.nlive) return;      // a chain of the layout that does not exist
-        leap_tile<TSM, NST>(d, c, w, s, ch, tile % d.ntc, tile / d.ntc, bz, par0, nsteps, step_base, role_base, fold);
+#if !defined(LEAP_PART) || LEAP_PART == 1
+        leap_tile<TSM, NST, RW>(d, c, w, s, ch, tile % d.ntc, tile / d.ntc, bz, par0, nsteps, step_base, role_base, fold);
+#endif
         return;
     }
+#if defined(LEAP_PART) && LEAP_PART == 1       // (developer builds: register use of the tile part alone)
+    return;
+#endif
     // a role: wave 0 runs it, the workgroup's other three waves share its loads of the tiles' partial sums (role_gather)
     __shared__ double gbuf[RoleGather<(NTC > 0 ? NTC : CT_MAXC)>::SIZE];
     const int L = (int)blockIdx.x - n_tiles;

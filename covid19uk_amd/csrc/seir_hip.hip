@@ -60,10 +60,19 @@ struct seir_ctx {
     int *eval_err = nullptr;          // k_eval_all: waits that timed out
     unsigned long long eval_a = 0, eval_b = 0;   // what a chain's counters A and B show after the launches so far
     int eval_nb = -1;                            // batch size of those launches (another size: counters and targets start over)
+    int eval_slots[2][2] = {{-1, -1}, {-1, -1}};  // workgroups of k_eval_all<GRAD, TN> the chip holds at once (occupancy API; [TN == 96][GRAD])
     std::vector<float> cstar32_host;        // fp32 copy of the padded Cstar, uploaded when the option is first set
 };
 
 static inline int ceil_to(int x, int q) { return (x + q - 1) / q * q; }
+
+// hipFuncSetAttribute applies to the current device's copy of a kernel: "done once" is kept per device (a bit per
+// ordinal), not per process
+#include <atomic>
+static bool first_on_device(std::atomic<unsigned long long> &mask, int device) {
+    const unsigned long long bit = 1ull << (device & 63);
+    return (mask.fetch_or(bit) & bit) == 0ull;
+}
 
 template <typename T>
 static int dev_alloc(seir_ctx *ctx, T **p, size_t count, bool zero = true) {
@@ -352,11 +361,9 @@ template <int TN>
 static void launch_gemm_t(seir_ctx *ctx, const LaunchCfg &l) {
     const Dims &d = l.d;
     const size_t lds = gemm_lds_bytes<TN>();
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static std::atomic<unsigned long long> attr_set{0ull};
+    if (lds > 64 * 1024 && first_on_device(attr_set, ctx->device))
         (void)hipFuncSetAttribute((const void *)k_gemm<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     hipLaunchKernelGGL((k_gemm<TN>), dim3(d.Tp / TN, d.Mp / GEMM_TM, l.nb), dim3(gemm_threads<TN>()), lds, l.st, d, ctx->c,
                        ctx->w);
 }
@@ -375,11 +382,9 @@ static void launch_gemm(seir_ctx *ctx, const LaunchCfg &l) {
     if (d.Tp % 96 == 0 && t64 > 256 && t96 <= 256) {
         // the eight-wave form of the 64 x 96 tile: every SIMD of a CU carries two waves (k_gemm<96>'s six waves: 2,2,1,1)
         const size_t lds = gemm_lds_bytes<96>();
-        static bool attr_set = false;
-        if (!attr_set && lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_set{0ull};
+        if (lds > 64 * 1024 && first_on_device(attr_set, ctx->device))
             (void)hipFuncSetAttribute((const void *)k_gemm_w8<GEMM_NCG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
         hipLaunchKernelGGL(k_gemm_w8<GEMM_NCG>, dim3(d.Tp / 96, d.Mp / GEMM_TM, l.nb), dim3(256 * GEMM_NCG), lds, l.st, d, ctx->c, ctx->w);
     } else {
         launch_gemm_t<64>(ctx, l);
@@ -443,11 +448,9 @@ extern "C" int seir_eval_prepared_dev(seir_ctx *ctx, int32_t B, const double *u_
 static void launch_state_params(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, const double *events_dev) {
     const Dims &d = l.d;
     const size_t lds_a = (size_t)SCAN_WAVES * d.Tp * 2 * sizeof(double);
-    static bool attr_a = false;
-    if (!attr_a && lds_a > 64 * 1024) {
+    static std::atomic<unsigned long long> attr_a{0ull};
+    if (lds_a > 64 * 1024 && first_on_device(attr_a, ctx->device))
         (void)hipFuncSetAttribute((const void *)k_state_params, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        attr_a = true;
-    }
     hipLaunchKernelGGL(k_state_params, dim3(d.nrb_scan + 1, l.nb), dim3(SCAN_WAVES * WAVE), lds_a, l.st, d, ctx->c, ctx->w,
                        events_dev, u_dev);
 }
@@ -508,11 +511,10 @@ static int launch_eval_all(seir_ctx *ctx, const LaunchCfg &l, const double *u_de
     ctx->eval_a += (unsigned long long)(per + 1);                       // per chain: the tiles' state parts + the parameter block
     ctx->eval_b += (unsigned long long)(per + d.nrb_scan + ncb);        //            tiles + row-constant blocks + I->R fold blocks
     const size_t lds = eval_all_lds_bytes<TN>(d);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
+    static std::atomic<unsigned long long> attr{0ull};
+    if (lds > 64 * 1024 && first_on_device(attr, ctx->device)) {
         (void)hipFuncSetAttribute((const void *)k_eval_all<true, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)k_eval_all<false, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
     }
     const dim3 grid((unsigned)((1 + per + d.nrb_scan + ncb + 1) * nbv));
     // the reduction block runs inside the launch for value-only calls; with the gradient it is its own launch (measured:
@@ -536,11 +538,10 @@ static void launch_eval_tiles(seir_ctx *ctx, const LaunchCfg &l, const double *e
     const bool affinity = (l.affinity & 1) && xcd_affinity_applies(d.ntc * d.nmt, B);
     d.aff_nb = affinity ? B : 0;
     const size_t lds_b = eval_tiles_lds_bytes<TN>();
-    static bool attr_b = false;
-    if (!attr_b && lds_b > 64 * 1024) {
+    static std::atomic<unsigned long long> attr_b{0ull};
+    if (lds_b > 64 * 1024 && first_on_device(attr_b, ctx->device)) {
         (void)hipFuncSetAttribute((const void *)k_eval_tiles<true, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
         (void)hipFuncSetAttribute((const void *)k_eval_tiles<false, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        attr_b = true;
     }
     const dim3 grid((unsigned)((d.ntc * d.nmt + d.nrb_scan + d.Tp / WAVE) * B));
     if (grad) hipLaunchKernelGGL((k_eval_tiles<true, TN>), grid, dim3(512), lds_b, l.st, d, ctx->c, ctx->w, events_dev, B);
@@ -583,9 +584,22 @@ extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, 
             const int tn = d.Tp % 96 == 0 ? 96 : 64;
             const int per1 = (d.Tp / tn) * (d.Mp / GEMM_TM);
             const int nbv = (B + 7) / 8 * 8;
-            int cus = 0;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-            if ((1 + per1) * nbv <= 2 * cus) {
+            // what the chip holds of this kernel at once: asked of the occupancy API with the launch's real dynamic LDS
+            // (cached per instance), not assumed
+            const int gi = grad_dev ? 1 : 0, ti = tn == 96 ? 1 : 0;
+            if (ctx->eval_slots[ti][gi] < 0) {
+                int occ = 0, cus = 0;
+                const void *fn = tn == 96 ? (grad_dev ? (const void *)k_eval_all<true, 96> : (const void *)k_eval_all<false, 96>)
+                                          : (grad_dev ? (const void *)k_eval_all<true, 64> : (const void *)k_eval_all<false, 64>);
+                Dims dq = d;
+                dq.nmt = d.Mp / GEMM_TM; dq.ntc = d.Tp / tn;
+                const size_t lds = tn == 96 ? eval_all_lds_bytes<96>(dq) : eval_all_lds_bytes<64>(dq);
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 512, lds) != hipSuccess) occ = 0;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+                ctx->eval_slots[ti][gi] = occ * cus;
+            }
+            if ((1 + per1) * nbv <= ctx->eval_slots[ti][gi]) {
                 if (ctx->xcd_local < 0) ctx->xcd_local = probe_xcd_local(ctx->stream) ? 1 : 0;
                 one = ctx->xcd_local == 1;
             }
@@ -962,6 +976,7 @@ struct seir_sampler {
     bool hmc_tail = true;         // hmc_mode 0 / 3: chunk roles inside the gradient launch (k_se_chunk) where xcd_local holds
     bool hmc_leap = true;         // hmc_mode 0: all inner steps in one persistent launch (k_leap) where every workgroup fits the chip
     int leap_occ[2][3][2];        // workgroups of k_leap<TSM, NTC, NST> the chip holds at once (occupancy query, cached; -1: not asked yet)
+    int leap_rows = 0;            // seir_sampler_desc::leap_rows: 0 auto, 24 / 32: only that tile shape (else the per-step form)
     // seir_sampler_time_leapfrog: HIP events around the inner leapfrog steps of each sweep while it is on
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after)
     int prof_i = -1, prof_launches = 0, prof_evals = 0;  // next pair to record (-1: off); launches / gradient evaluations of the section in the last sweep
@@ -981,14 +996,29 @@ struct seir_sampler {
     int graph_skew = 0, graph_aff = 3;   // context options the captured graph was built with
     bool have_state = false;
     double *ev_stage = nullptr;       // [B][M][T][3] fp64 staging for set/get_state
+    // --- recovery from a failed in-launch hand-off (seir_sampler_snapshot / _restore) ---
+    // Every device buffer of the sampler is one of: chain STATE (what the next sweep's draws are a function of: copied by a
+    // snapshot), HAND-OFF scratch (tokens, counters, descriptors in flight inside a sweep: zeroed by a restore, together
+    // with the host's running totals of the counters), or neither (trace, staging).
+    enum { R_OTHER = 0, R_STATE = 1, R_HANDOFF = 2 };
+    struct Region { void *p; size_t bytes; int kind; };
+    std::vector<Region> regions;
+    void *snap[2] = {nullptr, nullptr};   // shadow copies of the STATE regions, packed
+    bool snap_valid[2] = {false, false};
+    size_t snap_bytes = 0;
+    bool poisoned = false;            // a fatal hand-off time-out was reported: no sweeps until set_state / refresh / restore
+    int poison_chain = 0;
+    unsigned poison_count = 0;
+    int hmc_mode = 0;                 // the launch forms in force (seir_sampler_set_launch_form)
 };
 
 template <typename T>
-static int s_alloc(seir_sampler *s, T **p, size_t count) {
+static int s_alloc(seir_sampler *s, T **p, size_t count, int kind = seir_sampler::R_OTHER) {
     void *q = nullptr;
     const size_t bytes = (count ? count : 1) * sizeof(T);
     HIP_TRY(hipMalloc(&q, bytes));
     s->allocs.push_back(q);
+    s->regions.push_back({q, bytes, kind});
     HIP_TRY(hipMemset(q, 0, bytes));
     *p = (T *)q;
     return 0;
@@ -1013,11 +1043,23 @@ extern "C" void seir_sampler_destroy(seir_sampler *s) {
     if (s->ev_burst) (void)hipEventDestroy(s->ev_burst);
     if (s->ev_copy) (void)hipEventDestroy(s->ev_copy);
     for (void *p : s->allocs) (void)hipFree(p);
+    for (void *p : s->snap) if (p) (void)hipFree(p);
     Work &w = s->ctx->w;
     for (int x = 0; x < 3; ++x) { w.K[x] = nullptr; w.St[x] = nullptr; }
     w.rowtot = w.rngtot = nullptr;
     w.TS = w.sp = w.gst = w.Vt = w.acur = w.rirc = w.CT = w.CG = w.Lpart0 = nullptr;
     delete s;
+}
+
+// seir_sampler_desc::hmc_mode / moves_mode -> the switches enqueue_sweep reads
+static void apply_launch_form(seir_sampler *s, int hmc_mode, int moves_mode) {
+    s->hmc_mode = hmc_mode;
+    s->hmc_chunked = hmc_mode != 1;
+    s->hmc_tail = hmc_mode == 0 || hmc_mode == 3 || hmc_mode == 4 || hmc_mode == 5;
+    s->hmc_leap = hmc_mode == 0 || hmc_mode == 4 || hmc_mode == 5;
+    s->hmc_fold = hmc_mode == 0 || hmc_mode == 5;
+    s->hmc_end = hmc_mode == 0;
+    s->moves_mode = moves_mode;
 }
 
 extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, seir_sampler **out) {
@@ -1040,6 +1082,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->moves_mode < 0 || ds->moves_mode > 4 || ds->hmc_mode < 0 || ds->hmc_mode > 5)
         return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..5");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
+    if (ds->leap_rows != 0 && ds->leap_rows != 24 && ds->leap_rows != 32) return fail(SEIR_ERR_INVALID, "leap_rows is 0 (auto), 24 or 32");
     HIP_TRY(hipSetDevice(ctx->device));
     seir_sampler *s = new (std::nothrow) seir_sampler();
     if (!s) return fail(SEIR_ERR_DEVICE, "out of host memory");
@@ -1061,13 +1104,9 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     // kernels of ~10 us) stays ahead either way.  Default: stream launches; seir_sampler_desc::use_graph selects the graph.
     s->use_graph = ds->use_graph != 0;
     s->pair_debug = ds->debug_pair;
-    s->hmc_chunked = ds->hmc_mode != 1;
-    s->hmc_tail = ds->hmc_mode == 0 || ds->hmc_mode == 3 || ds->hmc_mode == 4 || ds->hmc_mode == 5;
-    s->hmc_leap = ds->hmc_mode == 0 || ds->hmc_mode == 4 || ds->hmc_mode == 5;
-    s->hmc_fold = ds->hmc_mode == 0 || ds->hmc_mode == 5;
-    s->hmc_end = ds->hmc_mode == 0;
+    s->leap_rows = ds->leap_rows;
+    apply_launch_form(s, ds->hmc_mode, ds->moves_mode);
     for (auto &a : s->leap_occ) for (auto &b2 : a) for (int &v : b2) v = -1;
-    s->moves_mode = ds->moves_mode;
     c.disable_mask = ds->disable_mask;
     {
         int g = ds->chain_groups;    // measured: concurrent chain groups on several streams do not overlap profitably
@@ -1083,44 +1122,46 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     const size_t cells = (size_t)ctx->Bmax * d.Mp * d.Tp;
     Chains &ch = s->ch;
 #define S_ALLOC(ptr, n) if (!rc) rc = s_alloc(s, &(ptr), (n))
-    for (int x = 0; x < 3; ++x) { S_ALLOC(w.K[x], cells); S_ALLOC(w.St[x], cells); }
-    S_ALLOC(w.rowtot, (size_t)ctx->Bmax * 2 * d.Mp);
-    S_ALLOC(w.rngtot, (size_t)ctx->Bmax * 2 * d.Mp);
+#define S_STATE(ptr, n) if (!rc) rc = s_alloc(s, &(ptr), (n), seir_sampler::R_STATE)
+#define S_HAND(ptr, n) if (!rc) rc = s_alloc(s, &(ptr), (n), seir_sampler::R_HANDOFF)
+    for (int x = 0; x < 3; ++x) { S_STATE(w.K[x], cells); S_STATE(w.St[x], cells); }
+    S_STATE(w.rowtot, (size_t)ctx->Bmax * 2 * d.Mp);
+    S_STATE(w.rngtot, (size_t)ctx->Bmax * 2 * d.Mp);
     S_ALLOC(w.TS, (size_t)ctx->Bmax * d.nmt * d.ntc * 4);
     S_ALLOC(w.Lpart0, (size_t)ctx->Bmax * d.nmt * d.ntc);
-    S_ALLOC(w.sp, (size_t)ctx->Bmax * 2 * d.Mp);
-    S_ALLOC(w.gst, (size_t)ctx->Bmax * 2 * GST_N);
-    S_ALLOC(w.Vt, (size_t)ctx->Bmax * d.Tp);
-    S_ALLOC(w.acur, (size_t)ctx->Bmax * d.Tp);
+    S_STATE(w.sp, (size_t)ctx->Bmax * 2 * d.Mp);
+    S_STATE(w.gst, (size_t)ctx->Bmax * 2 * GST_N);
+    S_STATE(w.Vt, (size_t)ctx->Bmax * d.Tp);
+    S_STATE(w.acur, (size_t)ctx->Bmax * d.Tp);
     S_ALLOC(w.rirc, (size_t)ctx->Bmax * 2 * d.Tp);
-    S_ALLOC(w.CT, (size_t)ctx->Bmax * 2 * CT_MAXC * 4);
-    S_ALLOC(w.CG, (size_t)ctx->Bmax * 2 * CT_MAXC * 2);
-    S_ALLOC(ch.q, (size_t)B * d.Pp); S_ALLOC(ch.p, (size_t)B * d.Pp); S_ALLOC(ch.q0, (size_t)B * d.Pp);
-    S_ALLOC(ch.grad, (size_t)B * d.Pp); S_ALLOC(ch.var, (size_t)B * d.Pp);
-    S_ALLOC(ch.rv_mean, (size_t)B * d.Pp); S_ALLOC(ch.rv_m2, (size_t)B * d.Pp);
-    S_ALLOC(ch.hs, (size_t)B * NHS);
-    S_ALLOC(ch.mv, (size_t)2 * B);
-    S_ALLOC(ch.fpend, (size_t)B);
-    S_ALLOC(ch.mvfix, (size_t)2 * B);
-    S_ALLOC(ch.mvsel, (size_t)2 * B);
-    S_ALLOC(ch.hand, (size_t)B);
-    S_ALLOC(ch.late, (size_t)2 * B);
+    S_STATE(w.CT, (size_t)ctx->Bmax * 2 * CT_MAXC * 4);
+    S_STATE(w.CG, (size_t)ctx->Bmax * 2 * CT_MAXC * 2);
+    S_STATE(ch.q, (size_t)B * d.Pp); S_STATE(ch.p, (size_t)B * d.Pp); S_STATE(ch.q0, (size_t)B * d.Pp);
+    S_STATE(ch.grad, (size_t)B * d.Pp); S_STATE(ch.var, (size_t)B * d.Pp);
+    S_STATE(ch.rv_mean, (size_t)B * d.Pp); S_STATE(ch.rv_m2, (size_t)B * d.Pp);
+    S_STATE(ch.hs, (size_t)B * NHS);
+    S_HAND(ch.mv, (size_t)2 * B);
+    S_HAND(ch.fpend, (size_t)B);
+    S_HAND(ch.mvfix, (size_t)2 * B);
+    S_HAND(ch.mvsel, (size_t)2 * B);
+    S_HAND(ch.hand, (size_t)B);
+    S_HAND(ch.late, (size_t)2 * B);
     ch.late_fatal = B;
-    S_ALLOC(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
-    S_ALLOC(ch.leap, (size_t)B * LEAP_CH);
-    S_ALLOC(ch.k0part, (size_t)B * 32);
-    S_ALLOC(ch.irl0, (size_t)B);
+    S_HAND(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
+    S_HAND(ch.leap, (size_t)B * LEAP_CH);
+    S_HAND(ch.k0part, (size_t)B * 32);
+    S_HAND(ch.irl0, (size_t)B);
     S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
-    S_ALLOC(ch.done, (size_t)B * 2 * TAIL_STRIDE);
-    S_ALLOC(ch.pbar, (size_t)B * PBAR_STRIDE);
-    S_ALLOC(ch.finpart, (size_t)B * 32 * 4);
-    S_ALLOC(ch.hand2, (size_t)B);
-    S_ALLOC(ch.mvs, (size_t)2 * B);
-    S_ALLOC(ch.DownS, (size_t)2 * B * 2);
-    S_ALLOC(ch.prev, (size_t)2 * B);
-    S_ALLOC(ch.Dpart, (size_t)B * c.nrb_d * 2);
-    S_ALLOC(ch.Down, (size_t)2 * 2 * B * 2);
-    S_ALLOC(ch.sweep, (size_t)B); S_ALLOC(ch.slot0, 1);
+    S_HAND(ch.done, (size_t)B * 2 * TAIL_STRIDE);
+    S_HAND(ch.pbar, (size_t)B * PBAR_STRIDE);
+    S_HAND(ch.finpart, (size_t)B * 32 * 4);
+    S_HAND(ch.hand2, (size_t)B);
+    S_HAND(ch.mvs, (size_t)2 * B);
+    S_HAND(ch.DownS, (size_t)2 * B * 2);
+    S_HAND(ch.prev, (size_t)2 * B);
+    S_HAND(ch.Dpart, (size_t)B * c.nrb_d * 2);
+    S_HAND(ch.Down, (size_t)2 * 2 * B * 2);
+    S_STATE(ch.sweep, (size_t)B); S_STATE(ch.slot0, 1);
     S_ALLOC(ch.tr_theta, (size_t)c.cap * B * d.P);
     {
         char *tre = nullptr;                               // bytes: int32 or uint16 per count
@@ -1131,6 +1172,20 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_ALLOC(ch.tr_hmc, (size_t)c.cap * B * 3);
     S_ALLOC(ch.tr_mv, (size_t)c.cap * B * 4 * NMVTR);
     S_ALLOC(s->ev_stage, (size_t)B * d.M * d.T * 3);
+#undef S_STATE
+#undef S_HAND
+    if (!rc) {
+        // chain state held in the context's own work arrays (written by accepted event updates and by the HMC roles):
+        // part of a snapshot too.  Sizes as in create_impl (max_chains chains).
+        const size_t Bm = (size_t)ctx->Bmax;
+        auto st_ = [&](void *p_, size_t bytes_) { s->regions.push_back({p_, bytes_, seir_sampler::R_STATE}); };
+        st_(w.F, cells * sizeof(double));
+        st_(w.rowconst, Bm * d.Mp * sizeof(double));
+        st_(w.ea, Bm * d.Tp * sizeof(double)); st_(w.eb, Bm * d.Mp * sizeof(double)); st_(w.rir, Bm * d.Tp * sizeof(double));
+        st_(w.scal, Bm * NSCAL * sizeof(double)); st_(w.Qs, Bm * d.Mp * sizeof(double));
+        st_(w.Kir, Bm * d.Tp * sizeof(double)); st_(w.Dir, Bm * d.Tp * sizeof(double));
+        st_(w.constsum, Bm * sizeof(double));
+    }
 #undef S_ALLOC
     if (!rc) {
         std::vector<double> ones((size_t)B * d.Pp, 1.0), hs((size_t)B * NHS, 0.0);
@@ -1169,6 +1224,95 @@ static int sampler_check(seir_sampler *s) {
     return 0;
 }
 
+// Hand-off scratch back to its initial state, in stream order: every token / counter / in-flight descriptor zero (0 is no
+// launch's token) and the host's running totals of the counters with them.  Between two sweeps nothing of it is live
+// (a sweep's first launch starts with have_prev = have_pre = 0), so this is always allowed there.
+static int reset_handoffs(seir_sampler *s) {
+    hipStream_t st = s->ctx->stream;
+    for (const auto &r : s->regions)
+        if (r.kind == seir_sampler::R_HANDOFF) HIP_TRY(hipMemsetAsync(r.p, 0, r.bytes, st));
+    s->leap_rsteps = s->leap_steps = 0;
+    s->tail_count = 0;
+    s->pbar_count = 0;
+    s->poisoned = false;
+    return 0;
+}
+
+extern "C" int seir_sampler_set_launch_form(seir_sampler *s, int32_t hmc_mode, int32_t moves_mode) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (moves_mode < 0 || moves_mode > 4 || hmc_mode < 0 || hmc_mode > 5)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..5");
+    if (hmc_mode != s->hmc_mode || moves_mode != s->moves_mode) {
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        drop_graph(s);                               // the captured sweep is one form's launches
+        apply_launch_form(s, hmc_mode, moves_mode);
+    }
+    return 0;
+}
+
+extern "C" int seir_sampler_launch_form(seir_sampler *s, int32_t *hmc_mode, int32_t *moves_mode) {
+    if (!s) return fail(SEIR_ERR_INVALID, "null sampler");
+    if (hmc_mode) *hmc_mode = s->hmc_mode;
+    if (moves_mode) *moves_mode = s->moves_mode;
+    return 0;
+}
+
+// Test hook: what a timed-out wait leaves behind -- chain `chain`'s fatal counter raised, in stream order.  Every wait of
+// that chain then gives up at its first look at the counter (a wait that is served within 256 polls still completes) and
+// the next read of the trace reports the time-out.
+extern "C" int seir_sampler_debug_fail_handoff(seir_sampler *s, int32_t chain) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (chain < 0 || chain >= s->cfg.B) return fail(SEIR_ERR_INVALID, "chain %d outside [0, %d)", chain, s->cfg.B);
+    static const uint32_t one = 1u;
+    HIP_TRY(hipMemcpyAsync(s->ch.late + s->ch.late_fatal + chain, &one, sizeof(one), hipMemcpyHostToDevice, s->ctx->stream));
+    return 0;
+}
+
+extern "C" int seir_sampler_snapshot(seir_sampler *s, int32_t slot) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (slot < 0 || slot > 1) return fail(SEIR_ERR_INVALID, "snapshot slot is 0 or 1");
+    if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
+    if (s->poisoned) return fail(SEIR_ERR_STATE, "the sampler's state is unreliable (hand-off time-out): nothing to snapshot");
+    if (!s->snap_bytes)
+        for (const auto &r : s->regions)
+            if (r.kind == seir_sampler::R_STATE) s->snap_bytes += (r.bytes + 255) / 256 * 256;
+    if (!s->snap[slot]) HIP_TRY(hipMalloc(&s->snap[slot], s->snap_bytes));
+    // in stream order: the snapshot is the state after everything queued so far
+    size_t off = 0;
+    for (const auto &r : s->regions)
+        if (r.kind == seir_sampler::R_STATE) {
+            HIP_TRY(hipMemcpyAsync((char *)s->snap[slot] + off, r.p, r.bytes, hipMemcpyDeviceToDevice, s->ctx->stream));
+            off += (r.bytes + 255) / 256 * 256;
+        }
+    s->snap_valid[slot] = true;
+    return 0;
+}
+
+extern "C" int seir_sampler_restore(seir_sampler *s, int32_t slot) {
+    int rc = sampler_check(s);
+    if (rc) return rc;
+    if (slot < 0 || slot > 1) return fail(SEIR_ERR_INVALID, "snapshot slot is 0 or 1");
+    if (!s->snap_valid[slot] || !s->snap[slot]) return fail(SEIR_ERR_STATE, "no snapshot in slot %d", slot);
+    hipStream_t st = s->ctx->stream;
+    // whatever is still queued (the rest of a failed burst: its waits give up at their first look at the chain's time-out
+    // counter, so it drains quickly) and the copy of a burst that nobody wants any more
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s->copy_pending) { (void)hipEventSynchronize(s->ev_copy); s->copy_pending = false; }
+    size_t off = 0;
+    for (const auto &r : s->regions)
+        if (r.kind == seir_sampler::R_STATE) {
+            HIP_TRY(hipMemcpyAsync(r.p, (const char *)s->snap[slot] + off, r.bytes, hipMemcpyDeviceToDevice, st));
+            off += (r.bytes + 255) / 256 * 256;
+        }
+    if ((rc = reset_handoffs(s))) return rc;
+    s->vt_dirty = true;                              // Work::Vt came back with the snapshot, the flag did not
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
 static void enqueue_refresh(seir_sampler *s) {
     seir_ctx *ctx = s->ctx;
     const Dims &d = ctx->d;
@@ -1187,6 +1331,10 @@ extern "C" int seir_sampler_refresh(seir_sampler *s) {
     int rc = sampler_check(s);
     if (rc) return rc;
     if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
+    if (s->poisoned) {
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        if ((rc = reset_handoffs(s))) return rc;
+    }
     enqueue_refresh(s);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1210,6 +1358,7 @@ extern "C" int seir_sampler_set_state(seir_sampler *s, const double *u, const do
                            ctx->stream));
     hipLaunchKernelGGL(k_import_events, dim3(1024), dim3(256), 0, ctx->stream, d, ctx->w, s->ev_stage, B);
     s->have_state = true;
+    if (s->poisoned && (rc = reset_handoffs(s))) return rc;
     enqueue_refresh(s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1386,8 +1535,11 @@ static void group_range(const seir_sampler *s, int g, int &b0, int &nb) {
 }
 
 // the instance of the persistent leapfrog kernel for (tile-scalar mode, day chunks, gradient tiles per workgroup)
+// nst = 2: two 16-row gradient tiles per workgroup (32 rows); nst = 1: ONE 24-row tile per workgroup, six rows per wave -- the
+// shape whose 96 workgroups per chain divide UK-380's XCD evenly (instantiated for that size class: M <= 512, six day chunks)
 static const void *leap_fn(int ts_mode, int ntc, int nst) {
-#define LEAP_ROW(TSM_, NTC_) ((void)nst, (const void *)k_leap<TSM_, NTC_, 2>)
+    if (nst == 1) return (const void *)k_leap<1, 6, 1, 6>;
+#define LEAP_ROW(TSM_, NTC_) ((const void *)k_leap<TSM_, NTC_, 2>)
     if (ts_mode == 1) return ntc == 1 ? LEAP_ROW(1, 1) : ntc == 6 ? LEAP_ROW(1, 6) : LEAP_ROW(1, 12);
     return ntc == 1 ? LEAP_ROW(2, 1) : ntc == 6 ? LEAP_ROW(2, 6) : LEAP_ROW(2, 12);
 #undef LEAP_ROW
@@ -1411,17 +1563,31 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     // one stream, the XCD-affine grid -- and every workgroup of the launch resident at once: its tiles wait for the roles)
     const int per_roles = d0.ntc + d0.Mp / WAVE, ntile_all = d0.ntc * d0.nmt, nbv_all = (nb + 7) / 8 * 8;
     bool leap_ok = false;
+    // the tile shape: 24-row workgroups (k_leap<1, 6, 1, 6>: nmt24 row tiles, one per workgroup) where they exist for the size
+    // and the whole launch -- three of them per CU and the roles beside -- is resident; else 32-row workgroups (two 16-row tiles)
+    int leap_nst = 2, leap_nmt = d0.nmt, leap_wgs = ntile_all / 2;
+    auto leap_slots = [&](int ti, int ni, int nst) {
+        int &slot = s->leap_occ[ti][ni][nst - 1];
+        if (slot < 0) {
+            int occ = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, leap_fn(ti + 1, ni == 0 ? 1 : ni == 1 ? 6 : 12, nst), 256, 0) != hipSuccess) occ = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            slot = occ * cus;                                     // workgroups the chip holds at once
+        }
+        return (long long)slot;
+    };
     if (chunked && s->hmc_leap && s->hmc_tail && s->xcd_local && s->ngroups == 1 && (l.affinity & 1) && !s->use_graph &&
         xcd_affinity_applies(ntile_all, nbv_all) && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && c.L >= 3 && d0.nmt <= WAVE &&
         d0.nmt % 2 == 0) {
         const int ti = ts_mode - 1, ni = d0.ntc == 1 ? 0 : d0.ntc == 6 ? 1 : 2;
-        if (s->leap_occ[ti][ni][1] < 0) {
-            int occ = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, leap_fn(ts_mode, d0.ntc, 2), 256, 0) != hipSuccess) occ = 0;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-            s->leap_occ[ti][ni][1] = occ * cus;                   // workgroups the chip holds at once
+        const int nmt24 = d0.Mp / 24, wgs24 = d0.ntc * nmt24;
+        if (s->leap_rows != 32 && ts_mode == 1 && d0.ntc == 6 && d0.Mp % 24 == 0 && xcd_affinity_applies(wgs24, nbv_all) &&
+            (long long)(wgs24 + per_roles) * nbv_all <= leap_slots(ti, ni, 1)) {
+            leap_ok = true;
+            leap_nst = 1; leap_nmt = nmt24; leap_wgs = wgs24;
+        } else if (s->leap_rows != 24) {
+            leap_ok = (long long)(ntile_all / 2 + per_roles) * nbv_all <= leap_slots(ti, ni, 2);
         }
-        leap_ok = (long long)(ntile_all / 2 + per_roles) * nbv_all <= (long long)s->leap_occ[ti][ni][1];
     }
     auto launch_leap = [&](int par0, int nsteps, int fold) {
         Dims df = l.d;
@@ -1429,13 +1595,14 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         df.nlive = nbv_all != nb ? nb : 0;
         df.sp_par = 0;
         df.chunked = ts_mode;
-        const dim3 gf((unsigned)((ntile_all / 2 + per_roles) * nbv_all));
+        df.nmt = leap_nmt;                                       // the partial sums of this launch: one set per row tile of ITS shape
+        const dim3 gf((unsigned)((leap_wgs + per_roles) * nbv_all));
         const unsigned long long step_base = s->leap_steps, role_base = s->leap_rsteps;
         s->leap_steps += (unsigned long long)nsteps;
         s->leap_rsteps += (unsigned long long)(nsteps - (((fold & 2) && !(fold & 4)) ? 1 : 0));
         void *args[] = {(void *)&df, (void *)&ctx->c, (void *)&ctx->w, (void *)&c, (void *)&s->ch, (void *)&par0, (void *)&nsteps,
                         (void *)&step_base, (void *)&role_base, (void *)&fold};
-        (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, 2), gf, dim3(256), args, 0, st);
+        (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, leap_nst), gf, dim3(256), args, 0, st);
     };
     const bool prof0 = s->prof_i >= 0 && (size_t)(2 * s->prof_i + 1) < s->prof_ev.size() && g == 0;
     const bool fold = leap_ok && s->hmc_fold;
@@ -1462,7 +1629,9 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         if (!s->hmc_end) {
             l.d.sp_par = c.L & 1 ? 0 : 1;       // the buffer the last role step wrote: steps alternate from buffer 1
             l.d.chunked = 0;
+            l.d.nmt = leap_nmt;                 // the end point's partial sums are k_leap's: its row tiles
             launch_hmc(ctx, l, c, s->ch, 2, /*gather_qs=*/3);
+            l.d.nmt = d0.nmt;
         }
     } else {
     l.d.chunked = 0;                       // k_se writes tile scalars only ahead of a chunked step
@@ -1647,11 +1816,13 @@ static void enqueue_sweep(seir_sampler *s, int g) {
     if (!advanced) hipLaunchKernelGGL(k_advance, dim3((nb + 63) / 64), dim3(64), 0, st, s->ch, b0, nb);
 }
 
+static int check_handoffs(seir_sampler *s);
 extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
     int rc = sampler_check(s);
     if (rc) return rc;
     if (!s->have_state) return fail(SEIR_ERR_STATE, "no chain state set");
     if (n < 0) return fail(SEIR_ERR_INVALID, "num_sweeps must be >= 0");
+    if (s->poisoned) return check_handoffs(s);       // sticky: see there
     hipStream_t main_st = s->ctx->stream;
     // fork: every group stream starts after what is already queued on the context stream
     HIP_TRY(hipEventRecord(s->ev_fork, main_st));
@@ -1689,18 +1860,27 @@ extern "C" int seir_sampler_run(seir_sampler *s, int32_t n) {
 // trusted -- the next read of the trace fails loudly instead of delivering them.
 static int check_handoffs(seir_sampler *s) {
     if (s->pair_debug != 0) return 0;                     // the hooks make roles late on purpose
-    // only the waits a workgroup cannot recover from (band tokens, k_se_chunk's tile flag); a late speculative role
-    // of k_move_pair is benign -- role 0 draws the proposal itself, the traces are the same -- and only counted
-    std::vector<uint32_t> late((size_t)s->cfg.B, 0u);
-    uint32_t *fatal = s->ch.late + s->ch.late_fatal;
-    HIP_TRY(hipMemcpy(late.data(), fatal, sizeof(uint32_t) * late.size(), hipMemcpyDeviceToHost));
-    for (size_t b = 0; b < late.size(); ++b)
-        if (late[b]) {
-            // reported once: the draws read by THIS call are the unreliable ones, later bursts start clean
-            HIP_TRY(hipMemset(fatal, 0, sizeof(uint32_t) * late.size()));
-            return fail(SEIR_ERR_STATE, "chain %d: %u in-launch hand-off(s) timed out -- draws since the last check are unreliable "
-                        "(hmc_mode 2 / moves_mode 3 select the multi-launch forms)", (int)b, late[b]);
-        }
+    // only the waits a workgroup cannot recover from (band tokens, k_se_chunk's tile flag, k_leap's flags, k_move_pairs'
+    // step barrier); a late speculative role of k_move_pair is benign -- role 0 draws the proposal itself, the traces
+    // are the same -- and only counted
+    if (!s->poisoned) {
+        std::vector<uint32_t> late((size_t)s->cfg.B, 0u);
+        uint32_t *fatal = s->ch.late + s->ch.late_fatal;
+        HIP_TRY(hipMemcpy(late.data(), fatal, sizeof(uint32_t) * late.size(), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < late.size(); ++b)
+            if (late[b]) { s->poisoned = true; s->poison_chain = (int)b; s->poison_count = late[b]; break; }
+    }
+    if (s->poisoned)
+        // STICKY: a workgroup that gave up a wait went on with stale data (a band workgroup with an old F-band descriptor:
+        // Work::F is only ever updated incrementally and would stay out of step with the event planes), so nothing this
+        // sampler produces is to be trusted until its state is rebuilt -- seir_sampler_restore (back to the last snapshot:
+        // the failed burst can be run again, e.g. in the per-step launch forms), seir_sampler_set_state or
+        // seir_sampler_refresh (F and every table recomputed from the planes as they are; the failed burst's draws are lost)
+        return fail(SEIR_ERR_STATE, "chain %d: %u in-launch hand-off(s) timed out -- the persistent launches could not get all "
+                    "their workgroups on the GPU at once (another sampler or process holds part of it?).  Draws since the last "
+                    "check are unreliable and the sampler refuses to go on until seir_sampler_restore / _set_state / _refresh; "
+                    "hmc_mode 3 + moves_mode 4 (seir_sampler_set_launch_form) are the launch forms for a shared GPU",
+                    s->poison_chain, s->poison_count);
     return 0;
 }
 

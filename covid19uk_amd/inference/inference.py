@@ -332,8 +332,21 @@ def trace_events_dtype(cases, choice="auto"):
     return "u16" if 16.0 * float(np.max(cases, initial=0.0)) < 65535.0 else True
 
 
+def launch_forms(lay, device_arg, hmc="auto", moves="auto", env=os.environ):
+    """The launch forms of the sampler for this process (`ChainSampler(hmc=..., moves=...)`).  "auto": the persistent
+    whole-chip launches ("chunk", "paired") when this rank has its GPU to itself, the per-step forms ("chunk-launch",
+    "paired-launch") when several ranks of the job were given the SAME device -- an explicit `--device` in a job with more
+    than one rank on the node: torchrun hands every rank the same command line -- because two persistent launches cannot
+    both be resident on one GPU (include/seir_hip.h, seir_sampler_desc::moves_mode).  Whatever is chosen here, a hand-off
+    time-out at run time makes `ChainSampler` fall back by itself."""
+    local_world = int(env.get("LOCAL_WORLD_SIZE", lay["world"]))
+    shared = lay["world"] > 1 and device_arg is not None and local_world > 1
+    return ("chunk-launch" if shared else "chunk") if hmc == "auto" else hmc, \
+           ("paired-launch" if shared else "paired") if moves == "auto" else moves
+
+
 def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool_step_size=False, init_jitter=0.0,
-         events_dtype="auto"):
+         events_dtype="auto", hmc="auto", moves="auto"):
     """Constructs and runs the MCMC (covid19uk/inference/inference.py:473-608).
 
     Multi-GPU: launched as one process per GPU, every rank runs `num_chains` chains with
@@ -364,10 +377,11 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool
             else:
                 dist.init_process_group(backend)
     model = SeirModel(cov, initial_state, max_chains=B, device=lay["device"])
+    hmc_form, moves_form = launch_forms(lay, device, hmc, moves)
     sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),
                            num_leapfrog_steps=hmc_kernel_kwargs_default()["num_leapfrog_steps"],
                            trace_capacity=cap, record_events=trace_events_dtype(cases, events_dtype),
-                           first_chain_id=lay["first_chain_id"])
+                           first_chain_id=lay["first_chain_id"], hmc=hmc_form, moves=moves_form)
     u0 = dispersed_start(P, [lay["first_chain_id"] + c for c in range(B)], float(init_jitter), seed)
     sampler.set_state(u0, np.stack([events] * B))
     print("Initial logpi:", sampler.log_prob(), flush=True)
@@ -377,6 +391,8 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool
     posteriors = [Posterior(name, M, T, cfg["m"], num_samples, burst=int(config["num_burst_samples"]))
                   for name in names]
     run_mcmc(sampler, config, posteriors, pool_step_size=pool_step_size and total > 1)
+    if sampler.recoveries:
+        print(f"{len(sampler.recoveries)} burst(s) were run again after a hand-off time-out (shared GPU?)", flush=True)
     for post in posteriors:
         post.create_dataset("initial_state", initial_state)
         n = max(len(s) for s in dates)
@@ -413,11 +429,19 @@ def main(argv=None):
     parser.add_argument("--events-dtype", choices=["auto", "u16", "int32"], default="auto",
                         help="width of the event counts in the device-side burst buffer (auto: 16 bit while 16 x the largest "
                              "observed count fits, else 32)")
+    from ..sampler import HMC_MODES, MOVES_MODES
+    parser.add_argument("--hmc", choices=["auto"] + sorted(HMC_MODES), default="auto",
+                        help="launch form of the HMC update (auto: the persistent whole-trajectory launch, or one launch per "
+                             "leapfrog step when ranks share a GPU); what is sampled does not depend on it")
+    parser.add_argument("--moves", choices=["auto"] + sorted(MOVES_MODES), default="auto",
+                        help="launch form of the event updates (auto: one persistent launch per sweep, or one launch per pair "
+                             "of updates when ranks share a GPU)")
     args = parser.parse_args(argv)
     with open(args.config, "r") as f:
         config = yaml.load(f, Loader=yaml.FullLoader)
     mcmc(args.data_file, args.output, config["Mcmc"], seed=args.seed, num_chains=args.chains, device=args.device,
-         pool_step_size=args.pool_step_size, init_jitter=args.init_jitter, events_dtype=args.events_dtype)
+         pool_step_size=args.pool_step_size, init_jitter=args.init_jitter, events_dtype=args.events_dtype,
+         hmc=args.hmc, moves=args.moves)
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import dataclasses
+import sys
 
 import numpy as np
 
@@ -19,6 +20,12 @@ from . import _lib
 from .seir import SeirModel, _dptr
 
 MOVE_KEYS = ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I")   # inference.py:277-280
+MOVES_MODES = {"paired": 0, "split": 1, "paired-nopre": 2, "paired-delta": 3, "paired-launch": 4}
+HMC_MODES = {"chunk": 0, "single": 1, "chunk-split": 2, "chunk-launch": 3, "chunk-leap": 4, "chunk-stage": 5}
+# Launch forms to fall back on when a hand-off inside a persistent launch times out (the GPU is shared with something):
+# first the per-step forms, whose waiting workgroups are always placed behind the ones they wait for, then the forms
+# without any hand-off inside a launch.  What is sampled is the same in all of them.
+FALLBACK_FORMS = (("chunk-launch", "paired-launch"), ("chunk-split", "paired-delta"))
 
 
 @dataclasses.dataclass
@@ -70,7 +77,8 @@ class ChainSampler:
                  t_range=None, num_leapfrog_steps: int = 16, trace_capacity: int = 100,
                  first_chain_id: int = 0, record_events: bool = True, moves: str = "paired",
                  hmc: str = "chunk", use_graph: bool = False, chain_groups: int = 1,
-                 disable: tuple = (), debug_pair: int = 0):
+                 disable: tuple = (), debug_pair: int = 0, auto_recover: bool = True, log=sys.stderr,
+                 leap_rows: int = 0):
         """`config` is the reference's config["Mcmc"] dict: dmax, nmax, m,
         occult_nmax, num_event_time_updates (mcmc_kernel_factory.py:79-81,106,123).
 
@@ -79,7 +87,13 @@ class ChainSampler:
         "split" (one proposal kernel per update, cross-check);
         `hmc` "chunk" (default) | "single"; `use_graph`; `chain_groups`.
         `disable`: sub-kernels that draw their proposal but always reject, any of
-        "hmc", "move/S->E", "move/E->I", "occult/S->E", "occult/E->I" (invariant-distribution tests)."""
+        "hmc", "move/S->E", "move/E->I", "occult/S->E", "occult/E->I" (invariant-distribution tests).
+
+        `auto_recover`: `sample` and `sample_bursts` snapshot the chain state at the start of every burst and, should a
+        hand-off inside a persistent launch time out (`_lib.HandoffTimeout`: the launch could not get all its workgroups on
+        the GPU -- another sampler or process holds part of it), restore it, switch to the per-step launch forms
+        (`FALLBACK_FORMS`), run the burst again and carry on; after `retry_after` clean bursts the preferred forms are tried
+        again (twice as many after every further failure).  Every recovery is logged and kept in `self.recoveries`."""
         names = ("hmc",) + MOVE_KEYS
         mask = 0
         for name in disable:
@@ -104,11 +118,18 @@ class ChainSampler:
             num_leapfrog_steps=int(num_leapfrog_steps), trace_capacity=self.cap,
             first_chain_id=int(first_chain_id), record_events=(2 if record_events == "u16" else int(self.record_events)),
             seed=int(seed) & (2 ** 64 - 1),
-            moves_mode={"paired": 0, "split": 1, "paired-nopre": 2, "paired-delta": 3, "paired-launch": 4}[moves], hmc_mode={"chunk": 0, "single": 1, "chunk-split": 2, "chunk-launch": 3, "chunk-leap": 4, "chunk-stage": 5}[hmc],
+            moves_mode=MOVES_MODES[moves], hmc_mode=HMC_MODES[hmc],
             use_graph=int(bool(use_graph)), chain_groups=int(chain_groups), disable_mask=mask,
-            debug_pair=int(debug_pair))
+            debug_pair=int(debug_pair), leap_rows=int(leap_rows))
         self._s = ctypes.c_void_p()
         _lib.check(self._lib.seir_sampler_create(model._ctx, ctypes.byref(desc), ctypes.byref(self._s)))
+        self.auto_recover = bool(auto_recover) and debug_pair == 0
+        self.preferred_form = (hmc, moves)
+        self.recoveries = []              # one dict per recovery: burst form that failed, form it was re-run in, message
+        self.retry_after = 8              # clean bursts in a fall-back form before the preferred one is tried again
+        self._fallback_level = 0          # 0: preferred form; k: FALLBACK_FORMS[k-1]
+        self._clean_bursts = 0
+        self._log = log
 
     def close(self):
         for bf in getattr(self, "_pinned", []):
@@ -152,6 +173,56 @@ class ChainSampler:
 
     def refresh(self):
         _lib.check(self._lib.seir_sampler_refresh(self._s))
+
+    # -- surviving a placement failure of the persistent launches (include/seir_hip.h) ----------------
+    def snapshot(self, slot: int = 0):
+        """Copy the chain state (everything the next sweep's draws are a function of; not the trace) to shadow slot 0 / 1,
+        in stream order."""
+        _lib.check(self._lib.seir_sampler_snapshot(self._s, int(slot)))
+
+    def restore(self, slot: int = 0):
+        """Back to the snapshot in `slot`; clears a hand-off time-out."""
+        _lib.check(self._lib.seir_sampler_restore(self._s, int(slot)))
+
+    def set_launch_form(self, hmc: str, moves: str):
+        _lib.check(self._lib.seir_sampler_set_launch_form(self._s, HMC_MODES[hmc], MOVES_MODES[moves]))
+
+    def launch_form(self):
+        h, m = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._lib.seir_sampler_launch_form(self._s, ctypes.byref(h), ctypes.byref(m)))
+        inv_h = {v: k for k, v in HMC_MODES.items()}
+        inv_m = {v: k for k, v in MOVES_MODES.items()}
+        return inv_h[h.value], inv_m[m.value]
+
+    def _recover(self, slot: int, err: Exception):
+        """A burst failed with a hand-off time-out: back to the snapshot taken at its start, one step down the ladder of
+        launch forms.  Raises `err` when there is nothing further down."""
+        if self._fallback_level >= len(FALLBACK_FORMS):
+            raise err
+        failed = self.launch_form()
+        self.restore(slot)
+        self._fallback_level += 1
+        form = FALLBACK_FORMS[self._fallback_level - 1]
+        self.set_launch_form(*form)
+        self._clean_bursts = 0
+        self.retry_after = min(2 * self.retry_after, 4096) if self.recoveries else self.retry_after
+        self.recoveries.append(dict(failed_form=failed, rerun_form=form, error=str(err)))
+        if self._log is not None:
+            print(f"[seir] hand-off time-out in launch form {failed}: the burst's draws are discarded, the chain state is "
+                  f"restored from the snapshot taken at its start and the burst runs again as {form}; the preferred form is "
+                  f"tried again after {self.retry_after} clean bursts ({err})", file=self._log, flush=True)
+
+    def _burst_ok(self):
+        """A burst was delivered: after enough clean ones in a fall-back form, try the preferred form again."""
+        if self._fallback_level == 0:
+            return
+        self._clean_bursts += 1
+        if self._clean_bursts >= self.retry_after:
+            self._fallback_level = 0
+            self._clean_bursts = 0
+            self.set_launch_form(*self.preferred_form)
+            if self._log is not None:
+                print(f"[seir] back to launch form {self.preferred_form}", file=self._log, flush=True)
 
     # -- kernel parameters -----------------------------------------------------
     def set_kernel(self, step_size=None, variance=None):
@@ -249,37 +320,69 @@ class ChainSampler:
             self._pinned_key = key
         bufs = self._pinned
         futs = [None, None]
-        prev = -1
+        # i: next burst to enqueue; prev: the burst whose copy is in flight (-1: none).  A hand-off time-out surfaces at
+        # trace_wait (or at the next call after it): the oldest burst not yet handed to `consume` is then run again from
+        # the snapshot taken at its start, in the next launch form down the ladder (_recover) -- and so is everything
+        # enqueued after it, which ran from a state that cannot be trusted.
+        i, prev, retried = 0, -1, -1
         try:
             with ThreadPoolExecutor(max_workers=1) as pool:
-                for i in range(num_bursts):
-                    h = i & 1
-                    if futs[h] is not None:
-                        futs[h].result()                 # the consumer is done with host buffer h
-                        futs[h] = None
-                    self.reset_trace(at=h * burst)
-                    self.run(burst)                      # asynchronous
-                    if prev >= 0:
-                        self.trace_wait()                # burst i-1 has landed (it crossed while burst i ran)
-                        futs[prev & 1] = pool.submit(consume, self.trace_view(bufs[prev & 1], burst), prev)
-                    self.read_trace_async(burst, h * burst, bufs[h])
-                    prev = i
-                if prev >= 0:
-                    self.trace_wait()
-                    futs[prev & 1] = pool.submit(consume, self.trace_view(bufs[prev & 1], burst), prev)
+                while i < num_bursts or prev >= 0:
+                    try:
+                        h = i & 1
+                        if i < num_bursts:
+                            if futs[h] is not None:
+                                futs[h].result()                 # the consumer is done with host buffer h
+                                futs[h] = None
+                            if self.auto_recover:
+                                self.snapshot(h)                 # stream order: the state burst i starts from
+                            self.reset_trace(at=h * burst)
+                            self.run(burst)                      # asynchronous
+                        if prev >= 0:
+                            self.trace_wait()                    # burst prev has landed (it crossed while burst i ran)
+                            futs[prev & 1] = pool.submit(consume, self.trace_view(bufs[prev & 1], burst), prev)
+                            prev = -1
+                            self._burst_ok()
+                        if i < num_bursts:
+                            self.read_trace_async(burst, h * burst, bufs[h])
+                            prev = i
+                            i += 1
+                    except _lib.HandoffTimeout as e:
+                        bad = prev if prev >= 0 else i
+                        if not self.auto_recover or bad >= num_bursts:
+                            raise
+                        if bad == retried and self._fallback_level >= len(FALLBACK_FORMS):
+                            raise
+                        retried = bad
+                        self._recover(bad & 1, e)
+                        i, prev = bad, -1
                 for f in futs:
                     if f is not None:
                         f.result()
         finally:
-            self.trace_wait()
+            try:
+                self.trace_wait()
+            except _lib.HandoffTimeout:
+                pass
 
     def sample(self, num_sweeps: int, events: bool = True) -> Trace:
         """reset_trace + run + read: the analogue of one `sample_chain` call."""
         if num_sweeps > self.cap:
             raise ValueError(f"num_sweeps={num_sweeps} exceeds trace_capacity={self.cap}")
-        self.reset_trace()
-        self.run(num_sweeps)
-        return self.read_trace(num_sweeps, events=events)
+        while True:
+            if self.auto_recover:
+                self.snapshot(0)
+            self.reset_trace()
+            self.run(num_sweeps)
+            try:
+                tr = self.read_trace(num_sweeps, events=events)
+            except _lib.HandoffTimeout as e:
+                if not self.auto_recover:
+                    raise
+                self._recover(0, e)          # raises e again when no launch form is left to fall back on
+                continue
+            self._burst_ok()
+            return tr
 
     def xcd_local(self) -> bool:
         """True if workgroups with ids congruent mod 8 share an XCD on this GPU (probed at creation): the condition for

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SEIR_ABI_VERSION 2
+#define SEIR_ABI_VERSION 3
 
 typedef enum {
     SEIR_OK = 0,
@@ -229,7 +229,13 @@ typedef struct {
                                        streams do not shift) but is always rejected -- used by the
                                        invariant-distribution tests to run each MH kernel alone */
     int32_t debug_pair;             /* test hooks of k_move_pair's handshake: 1 late, 2 absent speculative role */
-    int32_t reserved[2];
+    int32_t leap_rows;              /* tile shape of the persistent leapfrog launch (hmc_mode 0, 4, 5; speed only, same draws up
+                                       to the order of summation): 0 = auto -- workgroups of 24 rows x 64 days (six rows per
+                                       wave) where ceil64(M) is a multiple of 24 with M <= 512 and T in six 64-day chunks
+                                       (UK-380: 96 tile workgroups per chain, three on every CU of the chain's XCD) and the
+                                       launch is resident, else 32 rows (two 16-row tiles per workgroup); 24 / 32: that shape
+                                       only (the per-step form where it cannot be used) */
+    int32_t reserved[1];
 } seir_sampler_desc;
 
 int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *desc, seir_sampler **out);
@@ -303,17 +309,55 @@ int seir_sampler_xcd_local(seir_sampler *s);
 /* Time-outs of waits inside a launch, per chain: out [B] = (a) k_move_pair launches in which the
  * authoritative workgroup gave up waiting for a speculative one (it then draws the proposal itself:
  * results are unaffected, throughput is not) + (b) waits that cannot be recovered from (band tokens,
- * k_se_chunk's tile flag).  Only (b) makes the next seir_sampler_read_trace / seir_sampler_trace_wait
- * fail (once: the counter is cleared when reported); (a) is benign and only counted here.  Both stay
- * 0 outside the debug_pair test hooks. */
+ * k_se_chunk's tile flag, k_leap's flags, k_move_pairs' step barrier).  (a) is benign and only counted
+ * here.  (b) makes the next seir_sampler_read_trace / seir_sampler_trace_wait fail with SEIR_ERR_STATE
+ * and the error is STICKY: a workgroup that gave up went on with stale data (the incrementally updated
+ * F = Cstar . I/N can be out of step with the event planes afterwards), so seir_sampler_run and every read
+ * of the trace keep failing until seir_sampler_restore, seir_sampler_set_state or seir_sampler_refresh has
+ * rebuilt the state.  Both counts stay 0 outside the debug_pair test hooks and a GPU shared with
+ * another persistent launch. */
 int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out);
 
 /* Measurement hook (no reference counterpart): runs `sweeps` ordinary sweeps with a pair of HIP events around the
- * inner leapfrog steps 1..L-1 of each -- the section in which 15 of the sweep's 17 gradient evaluations happen -- on
- * the stream the kernels are launched on.  mean_ms = mean duration of that section; launches = kernel launches in it
- * (1: the persistent k_leap, L-1: k_se_chunk per step, 2(L-1): k_se + k_hmc_chunk); evals = gradient evaluations in
- * it (L-1).  The chains advance as in seir_sampler_run. */
+ * leapfrog section of each, on the stream the kernels are launched on.  What the section is depends on the launch form
+ * in force:
+ *   hmc_mode 0 (default, where it fits)  ONE launch, the persistent k_leap: the whole trajectory -- all L+1 gradient
+ *                                        evaluations, the L leapfrog steps, accept test, adaptation and trace:
+ *                                        launches = 1, evals = L+1;
+ *   hmc_mode 5                           the same launch without the trajectory's end: launches = 1, evals = L+1;
+ *   hmc_mode 4                           k_leap for the inner steps 1..L-1 only: launches = 1, evals = L-1;
+ *   hmc_mode 3 / 2                       the inner steps 1..L-1 as one k_se_chunk launch each (launches = L-1) or as
+ *                                        k_se + k_hmc_chunk (launches = 2(L-1)): evals = L-1.
+ * mean_ms = mean duration of that section.  The chains advance as in seir_sampler_run. */
 int seir_sampler_time_leapfrog(seir_sampler *s, int32_t sweeps, float *mean_ms, int32_t *launches, int32_t *evals);
+
+/* ------------------------------------------------------------------------
+ * Surviving a placement failure of the persistent launches (no reference counterpart: the reference carries
+ * `current_state` and the kernel results in host memory from burst to burst, inference.py:457-458, and cannot lose
+ * a run to what else is on the GPU).
+ *
+ * hmc_mode 0 and moves_mode 0 need every workgroup of their launch resident at once; a second sampler, another
+ * process or a profiler's replay pass can leave part of a grid unplaced, the bounded waits then time out and the
+ * sampler reports SEIR_ERR_STATE (see seir_sampler_pair_timeouts).  The burst loop of inference.py:453-468 is kept
+ * alive like this:
+ *     seir_sampler_snapshot(s, k & 1)            at the start of burst k (in stream order, a few device copies)
+ *     seir_sampler_run(s, n); read the trace
+ *     on SEIR_ERR_STATE:  seir_sampler_restore(s, k & 1);  seir_sampler_set_launch_form(s, 3, 4);  run burst k again
+ * A snapshot holds everything the next sweep's draws are a function of (event planes, state planes, F, the
+ * tables, position, step size, adaptation state, sweep counter) -- not the trace.  After a restore the same
+ * launch form reproduces the burst bit for bit, the per-step forms (hmc_mode 3, moves_mode 4) draw for draw with
+ * continuous quantities equal up to the order of summation.  Two slots, so that a burst that is still being
+ * copied out can be re-run as well.
+ * ------------------------------------------------------------------------ */
+int seir_sampler_snapshot(seir_sampler *s, int32_t slot /* 0 or 1 */);
+int seir_sampler_restore(seir_sampler *s, int32_t slot);
+/* Change the launch form (seir_sampler_desc::hmc_mode / moves_mode) of an existing sampler; what is sampled does not
+ * change.  seir_sampler_launch_form reads the form in force. */
+int seir_sampler_set_launch_form(seir_sampler *s, int32_t hmc_mode, int32_t moves_mode);
+int seir_sampler_launch_form(seir_sampler *s, int32_t *hmc_mode, int32_t *moves_mode);
+/* Test hook: raises chain `chain`'s fatal time-out counter in stream order, i.e. leaves what a timed-out wait leaves.
+ * The sweeps queued behind it run with every long wait of that chain cut short and the next read of the trace fails. */
+int seir_sampler_debug_fail_handoff(seir_sampler *s, int32_t chain);
 
 /* ------------------------------------------------------------------------
  * Reproduction number R_it.

@@ -39,7 +39,7 @@ def test_header_symbols_are_exported(lib):
 def test_abi_version(lib):
     text = open(os.path.join(ROOT, "include", "seir_hip.h")).read()
     declared = int(re.search(r"#define\s+SEIR_ABI_VERSION\s+(\d+)", text).group(1))
-    assert lib.seir_abi_version() == declared == _lib.ABI_VERSION == 2
+    assert lib.seir_abi_version() == declared == _lib.ABI_VERSION == 3
 
 
 def test_sampler_desc_struct_layout_matches_header():

@@ -11,6 +11,7 @@ from covid19uk_amd import synth
 from covid19uk_amd.sampler import ChainSampler
 from covid19uk_amd.seir import SeirModel
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ROWS = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # tile shape of k_leap: 0 auto, 24, 32
 cfg = dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5)
 cov = synth.make_covariates("uk380")
 events, init, truth = synth.simulate_epidemic(cov)
@@ -20,7 +21,7 @@ ev = np.stack([events] * B)
 lib = _lib.load()
 lib.seir_debug_leap_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 with SeirModel(cov, init, max_chains=B) as model:
-    with ChainSampler(model, cfg, B, seed=1, trace_capacity=50, record_events=False) as s:
+    with ChainSampler(model, cfg, B, seed=1, trace_capacity=50, record_events=False, leap_rows=ROWS, log=None) as s:
         s.set_state(u, ev); s.set_kernel(step_size=1.2e-5)
         s.run(20); model.sync()
         out = np.zeros((B + 2) * 128 + 4096, dtype=np.uint64)
