@@ -995,6 +995,7 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
     debug_skew(d);
     const int b = d.b0 + bz, m0 = by * GEMM_TM, t0 = bx * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int wr = wave / NCG, wc = wave % NCG;        // row block (16 rows), column group (CW columns)
     const double *Xb = w.Xn + (size_t)b * d.Mp * d.Tp;
     constexpr int EA = GSE_KC * (GEMM_TM / 2), EB = GSE_KC * (TN / 2);
@@ -1044,13 +1045,21 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
     if (tid < LDSTAB_N) ltab[tid] = c.logtab[tid];
     // the tile's slices of the parameter tables: read from LDS by the epilogue instead of living in registers
     // through the matrix loop
-    if (tid >= 256 && tid < 256 + TN) {
-        vec_t[tid - 256] = w.ea[(size_t)b * d.Tp + t0 + tid - 256];
-        vec_t[TN + tid - 256] = c.W[t0 + tid - 256];
-    }
-    if (tid >= 384 && tid < 384 + GEMM_TM) {
-        vec_m[tid - 384] = w.eb[(size_t)b * d.Mp + m0 + tid - 384];
-        vec_m[GEMM_TM + tid - 384] = c.N[m0 + tid - 384];
+    // (two disjoint thread ranges, each with its own loads: written as one `if / else if` over a common index the
+    // compiler selected the base addresses through a two-entry array in scratch memory -- TN = 64)
+    {
+        const int it_ = tid - 256, im_ = tid - (256 + TN);
+        if (it_ >= 0 && it_ < TN) {
+            const double ea_ = w.ea[(size_t)b * d.Tp + t0 + it_], w_ = c.W[t0 + it_];
+            vec_t[it_] = ea_;
+            vec_t[TN + it_] = w_;
+        }
+        asm volatile("" ::: "memory");
+        if (im_ >= 0 && im_ < GEMM_TM) {
+            const double eb_ = w.eb[(size_t)b * d.Mp + m0 + im_], n_ = c.N[m0 + im_];
+            vec_m[im_] = eb_;
+            vec_m[GEMM_TM + im_] = n_;
+        }
     }
     // K runs to Kp rounded up to a PAIR of chunks: Cstar and Xn are allocated and zero up to Mp = ceil64(M) rows,
     // so the extra rows add exact zeros
@@ -1096,8 +1105,13 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
     const double psi = w.scal[(size_t)b * NSCAL + SC_PSI];
     mfma_chunk(1);
     lds_barrier();                                   // the panels are dead: their LDS carries the tile and the reductions
+    // The thread index of the epilogue's reductions, formed again from the wave's number (a scalar since before the matrix
+    // loop) and the lane's position in the wave: kept alive through the loop it was the register pair the allocator parked
+    // in scratch memory (a private segment for one store and one load per launch).
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int tid_e = wave_s * WAVE + lane_e;
     // The accumulators go to LDS and the cells are evaluated by a rolled loop over the column blocks: unrolled, the
-    // twelve cells of a lane (each with its series / libm branch) need far more than the 128 registers that let a
+    // twelve cells of a lane_e (each with its series / libm branch) need far more than the 128 registers that let a
     // row-constant workgroup share the CU.
     constexpr int FS = TN + 2;
     double *Ft = lds;                                // [64][FS]
@@ -1107,7 +1121,7 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Ft[(lr0 + 4 * r) * FS + lc0 + 16 * j] = acc[j][r];
-    // each lane reads back exactly what it wrote: no barrier
+    // each lane_e reads back exactly what it wrote: no barrier
     double ll = 0.0, gpsi = 0.0;
     int nbad = 0;
     // Hot pass: every cell through the small-rate series, no branch in the cell code (cells interleave freely and the
@@ -1151,18 +1165,23 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ks[r] = ksn[r]; xn[r] = xnn[r]; }
     }
-    // Cold pass, only in a wave that counted such a cell (large hazards, or the NaN of a negative rate): the cells
+    // Cold pass, only in a wave_s that counted such a cell (large hazards, or the NaN of a negative rate): the cells
     // again, one at a time, those outside the range through l1me_inv's libm branch.
     if (__builtin_amdgcn_ballot_w64(nbad != 0) != 0) {
+        // (the cell index formed again from the local row: held for this rare block, the 64-bit index of the hot pass was
+        // the register pair parked in scratch memory in the 64-day instance)
+        int lr0c = lr0, lc0c = lc0;
+        asm volatile("" : "+v"(lr0c), "+v"(lc0c));
+        const size_t q00c = ((size_t)b * d.Mp + m0 + lr0c) * d.Tp + t0 + lc0c;
 #pragma unroll 1
         for (int cell = 0; cell < 4 * NJ; ++cell) {
             const int j = cell >> 2, r = cell & 3;
-            const size_t q = q00 + (size_t)(4 * r) * d.Tp + 16 * j;
+            const size_t q = q00c + (size_t)(4 * r) * d.Tp + 16 * j;
             const double F = w.F[q];                              // this thread's own store above
             const v2i k2 = *(const v2i *)(w.KS + q);
-            const double Wt = vec_t[TN + lc0 + 16 * j];
-            const double I = rint(w.Xn[q] * vec_m[GEMM_TM + lr0 + 4 * r]), kse = (double)k2.x, snk = (double)k2.y;
-            const double ee = vec_t[lc0 + 16 * j] * vec_m[lr0 + 4 * r];
+            const double Wt = vec_t[TN + lc0c + 16 * j];
+            const double I = rint(w.Xn[q] * vec_m[GEMM_TM + lr0c + 4 * r]), kse = (double)k2.x, snk = (double)k2.y;
+            const double ee = vec_t[lc0c + 16 * j] * vec_m[lr0c + 4 * r];
             const double lam0 = ee * (I + psi * Wt * F);
             const double rr = (lam0 + d.rate_floor) * d.dt;
             if (!(rr >= L1ME_SERIES_MIN && rr <= L1ME_SERIES_MAX)) {
@@ -1172,7 +1191,7 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
                 ll += (has ? kse * L : 0.0) - snk * rr;
                 if (GRAD) {
                     const double gl = d.dt * ((has ? kse * inv : 0.0) - snk);
-                    Ft[(lr0 + 4 * r) * FS + lc0 + 16 * j] = gl * lam0;
+                    Ft[(lr0c + 4 * r) * FS + lc0c + 16 * j] = gl * lam0;
                     gpsi += gl * ee * Wt * F;
                 }
             }
@@ -1180,10 +1199,10 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
     }
     ll = wave_sum(ll);
     if (GRAD) gpsi = wave_sum(gpsi);
-    if (lane == 0) { ep_sc[wave * 2] = ll; ep_sc[wave * 2 + 1] = gpsi; }
+    if (lane_e == 0) { ep_sc[wave_s * 2] = ll; ep_sc[wave_s * 2 + 1] = gpsi; }
     __syncthreads();
     const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
-    if (tid == 0) {
+    if (tid_e == 0) {
         double a = 0.0, g = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { a += ep_sc[k * 2]; g += ep_sc[k * 2 + 1]; }
@@ -1194,7 +1213,7 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
         // column sums (d/d eta over the tile's 64 rows, per day) and row sums (over its TN days, per row) of the LDS tile
         {
             // all 512 threads: 8 lanes per row, each adds TN/8 entries; then the 8 lanes combine by shuffles
-            const int i = tid >> 3, s8 = tid & 7;
+            const int i = tid_e >> 3, s8 = tid_e & 7;
             const double *src = Ft + i * FS + s8;
             double v = 0.0;
 #pragma unroll
@@ -1206,7 +1225,7 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
         }
         {
             // 4 row groups of 16 per column: TN x 4 threads (TN = 96: 384, TN = 64: 256), combined through LDS
-            const int t = tid % TN, g4 = tid / TN;
+            const int t = tid_e % TN, g4 = tid_e / TN;
             if (g4 < 4) {
                 const double *src = Ft + (g4 * 16) * FS + t;
                 double v0 = 0.0, v1 = 0.0;
@@ -1215,9 +1234,9 @@ __device__ __forceinline__ void gemm_se_tile(const Dims &d, const Consts &c, con
                 ep_col[g4 * TN + t] = v0 + v1;
             }
             __syncthreads();
-            if (tid < TN)
-                w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t0 + tid] =
-                    (ep_col[tid] + ep_col[TN + tid]) + (ep_col[2 * TN + tid] + ep_col[3 * TN + tid]);
+            if (tid_e < TN)
+                w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t0 + tid_e] =
+                    (ep_col[tid_e] + ep_col[TN + tid_e]) + (ep_col[2 * TN + tid_e] + ep_col[3 * TN + tid_e]);
         }
     }
 }
@@ -1429,9 +1448,13 @@ __global__ __launch_bounds__(256) void k_finish(Dims d, Consts c, Work w, const 
 // it while every tile workgroup of the launch can be resident (a tile waits for its chain's state while it holds a slot).
 // ---------------------------------------------------------------------------
 constexpr int EVC_STRIDE = 32;          // 64-bit words per chain: counters A and B in lines of their own
-__device__ __forceinline__ void evc_arrive(unsigned long long *p_) {
+// (`first`: the workgroup's thread 0, found from the wave's number -- a scalar since the kernel's first instruction -- and the
+// lane's position instead of threadIdx.x, which would otherwise be kept in a vector register through the tile's matrix loop
+// just for this; there it was the value the allocator parked in scratch memory)
+__device__ __forceinline__ void evc_arrive(unsigned long long *p_, int wave_s) {
     __syncthreads();                                   // vmcnt(0): this block's stores are in the XCD's L2
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(p_, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool first = wave_s == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;
+    if (first) __hip_atomic_fetch_add(p_, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void evc_wait(const unsigned long long *p_, unsigned long long target, int *err) {
     if (threadIdx.x == 0) {
@@ -1454,6 +1477,7 @@ void k_eval_all(Dims d, Consts c, Work w, const double *__restrict__ events, con
 #define ESTAMP(i) do {} while (0)
 #endif
     const int NB = d.aff_nb;                                // chains of the layout: a multiple of 8
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int per = d.ntc * d.nmt, ncb = d.Tp / WAVE;
     const int nP = NB, nT = per * NB, nC = d.nrb_scan * NB, nR = ncb * NB;
     int L = blockIdx.x;
@@ -1465,7 +1489,7 @@ void k_eval_all(Dims d, Consts c, Work w, const double *__restrict__ events, con
         __shared__ double seg[256];
         if (threadIdx.x >= 256) return;                     // param_tables is written for 256 threads
         param_tables(d, c, w, d.b0 + chain, u_all + (size_t)(d.b0 + chain) * d.P, seg, sh);
-        evc_arrive(cA);
+        evc_arrive(cA, wave_s);
         return;
     }
     L -= nP;
@@ -1488,18 +1512,18 @@ void k_eval_all(Dims d, Consts c, Work w, const double *__restrict__ events, con
             }
         }
         ESTAMP(1);
-        evc_arrive(cA);
+        evc_arrive(cA, wave_s);
         evc_wait(cA, targetA, err);
         ESTAMP(2);
         gemm_se_tile<GRAD, TN>(d, c, w, tile % d.ntc, tile / d.ntc, chain);
         ESTAMP(3);
-        evc_arrive(cB);
+        evc_arrive(cB, wave_s);
         return;
     }
     L -= nT;
     if (L < nC) {
         scan_rows<0, 2>(d, c, w, events, L / NB, chain);
-        evc_arrive(cB);
+        evc_arrive(cB, wave_s);
         return;
     }
     L -= nC;
@@ -1507,7 +1531,7 @@ void k_eval_all(Dims d, Consts c, Work w, const double *__restrict__ events, con
         evc_wait(cA, targetA, err);
         if (threadIdx.x >= 256) return;                     // colreduce_block is written for 256 threads
         colreduce_block(d, w, L / NB, chain, /*with_const=*/false);
-        evc_arrive(cB);
+        evc_arrive(cB, wave_s);
         return;
     }
     if (!do_finish) return;

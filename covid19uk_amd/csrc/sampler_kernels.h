@@ -1760,7 +1760,8 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
     static_assert(NST * TM <= WAVE, "one wave fetches the rows' table entries");
     auto LDP = [](const double *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     debug_skew(d);
-    const int b = d.b0 + bz, wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    const int b = d.b0 + bz, wave0 = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    const int wave = wave0;                                      // (ahead of the step loop; inside it: an opaque copy)
     const int t0 = bx * WAVE + lane0;
     const int mg = byg * NST * TM;                            // first row of the workgroup's tiles
     const int ntile = d.ntc * d.nmt, nwg = ntile / NST;          // gradient tiles / tile workgroups of a chain
@@ -1800,7 +1801,7 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
     // them in EVERY step (20 B per lane in the 32-row form, 60-190 B in the 24-row form at 128 registers).  As passes of
     // their own before and after the loop they cost the hot path nothing.  Same operations on the same operands as
     // se_cells / se_cells_L, the sums in the order the in-loop block formed them: the same bits.
-    auto ll_pass = [&](double *Lp) {
+    auto ll_pass = [&](double *Lp, int wave, int lane0) {
         SeK sk;
         sk.load();
         const double psiW = tabbuf[TB_PSI] * Wt, ea_t = tabbuf[lane0];
@@ -1857,15 +1858,17 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
     if (fold & 1) {                                              // the start point's value: before the first step
         fetch_tables(lane0, t0, par0, true);
         __syncthreads();
-        ll_pass(w.Lpart0);
+        ll_pass(w.Lpart0, wave0, lane0);
         __syncthreads();                                         // (tabbuf and llbuf are written again by the first step)
     }
     for (int it = 0; it < nsteps; ++it) {
         const int par = par0 ^ (it & 1);
         // (opaque copies made inside the loop: the per-lane addresses of the step are then not loop-invariant for the
         // compiler, which would otherwise hoist a few dozen of them out of the loop and spill them)
-        int lane = lane0, t = t0;
-        asm volatile("" : "+v"(lane), "+v"(t));
+        // (the wave index too: as a loop invariant it took the LDS and global base addresses of the step's reductions
+        // with it, and two of those register pairs were parked in scratch across the loop)
+        int lane = lane0, t = t0, wave = wave0;
+        asm volatile("" : "+v"(lane), "+v"(t), "+v"(wave));
         {
             // every wave waits (from the second step on) for the tables of this step's position, written by the roles of
             // step it-1, and fetches its share: four requests per workgroup
@@ -1996,7 +1999,7 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
         LPROBE(4);                                               // wave 0's reductions issued
         if ((fold & 2) && it == nsteps - 1) {                    // the end point: its value as well, before the tile counts in
             __syncthreads();                                     // (llbuf: nobody reads the step's LDS sums any more)
-            ll_pass(w.Lpart);
+            ll_pass(w.Lpart, wave, lane);
         }
         __syncthreads();                                         // vmcnt(0): this step's partial sums are in the XCD's L2
         LPROBE(5);                                               // stores acknowledged
@@ -2048,9 +2051,18 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
     // a role: wave 0 runs it, the workgroup's other three waves share its loads of the tiles' partial sums (role_gather)
     __shared__ double gbuf[RoleGather<(NTC > 0 ? NTC : CT_MAXC)>::SIZE];
     const int L = (int)blockIdx.x - n_tiles;
-    const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
+    const int bz = L % d.aff_nb, role_in = L / d.aff_nb, b_in = d.b0 + bz;
+    const int role = role_in, b = b_in;
     if (d.nlive > 0 && bz >= d.nlive) return;
     debug_skew(d);
+    // A role shares its SIMDs with tile waves (three of them per SIMD in the 24-row form) that are bound by instruction issue
+    // and OLDER than it: issue goes to the oldest wave first, and the role's loads and address arithmetic ahead of its wait
+    // were served in the gaps the tiles left -- an M-chunk role reached its wait 5.2 us into a step whose tiles were all in
+    // at 3.8 (tools/dev/leap_timeline.py).  The roles are the serial part of a step: they go first.
+#ifndef LEAP_ROLE_PRIO
+#define LEAP_ROLE_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(LEAP_ROLE_PRIO);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane_w = (int)(threadIdx.x & 63);
     const int nsh = min(LEAP_NSH, nwg);
@@ -2066,6 +2078,10 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         // nothing of a role lives across the steps: without this the compiler hoists the step-invariant loads of the role
         // (variances, V(t), the I->R statistics, CAR rows ...) out of the loop and spills 500+ bytes per lane to hold them
         asm volatile("" ::: "memory");
+        // ... and nothing derived from the chain or the role either: scalar addresses of the role's three dozen arrays,
+        // computed once ahead of the loop, were 70 of the ~370 SGPRs this kernel spills to vector lanes
+        int b = b_in, role = role_in;
+        asm volatile("" : "+s"(b), "+s"(role));
         const int par = par0 ^ (it & 1);
         const unsigned long long stepno = step_base + (unsigned long long)(it + 1);      // what the tiles' flags show
         const unsigned long long rstep = role_base + (unsigned long long)(it + 1);       // what the roles' flag will show

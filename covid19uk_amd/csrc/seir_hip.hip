@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -68,7 +69,6 @@ static inline int ceil_to(int x, int q) { return (x + q - 1) / q * q; }
 
 // hipFuncSetAttribute applies to the current device's copy of a kernel: "done once" is kept per device (a bit per
 // ordinal), not per process
-#include <atomic>
 static bool first_on_device(std::atomic<unsigned long long> &mask, int device) {
     const unsigned long long bit = 1ull << (device & 63);
     return (mask.fetch_or(bit) & bit) == 0ull;
@@ -98,8 +98,10 @@ static int dev_upload(seir_ctx *ctx, const T **p, const std::vector<T> &h) {
 extern "C" int seir_abi_version(void) { return SEIR_ABI_VERSION; }
 extern "C" const char *seir_last_error(void) { return g_err; }
 
+static void release_eval_all(seir_ctx *ctx);
 extern "C" void seir_destroy(seir_ctx *ctx) {
     if (!ctx) return;
+    release_eval_all(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->allocs) (void)hipFree(p);
@@ -482,6 +484,20 @@ static bool probe_xcd_local(hipStream_t st) {
     return ok;
 }
 
+// which context may use the one-launch evaluation on each device (see seir_log_prob_dev)
+static std::atomic<seir_ctx *> g_eval_all_owner[64];
+static bool claim_eval_all(seir_ctx *ctx) {
+    std::atomic<seir_ctx *> &slot = g_eval_all_owner[ctx->device & 63];
+    seir_ctx *cur = slot.load();
+    if (cur == ctx) return true;
+    if (cur != nullptr) return false;
+    return slot.compare_exchange_strong(cur, ctx) || cur == ctx;
+}
+static void release_eval_all(seir_ctx *ctx) {
+    seir_ctx *me = ctx;
+    (void)g_eval_all_owner[ctx->device & 63].compare_exchange_strong(me, nullptr);
+}
+
 template <int TN>
 static void launch_finish_fused(seir_ctx *ctx, const LaunchCfg &l, const double *u_dev, double *logp_dev, double *grad_dev);
 // The whole evaluation in one launch (k_eval_all): 8 chains, XCD-affine block ids, the GPU's XCD placement checked.
@@ -599,7 +615,12 @@ extern "C" int seir_log_prob_dev(seir_ctx *ctx, int32_t B, const double *u_dev, 
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
                 ctx->eval_slots[ti][gi] = occ * cus;
             }
-            if ((1 + per1) * nbv <= ctx->eval_slots[ti][gi]) {
+            // ... and ONE context per device: the launch's tiles wait, holding their CUs, for workgroups of the same launch; two
+            // such launches from two contexts' streams can each be placed in part and wait for the other's CUs (three
+            // contexts used in turn: 45 - 152 us per launch, sigma 32 us, profiles/r03_bench_kernel_stats.csv).  The
+            // first context to get here owns the one-launch form on its device until it is destroyed; the others run the
+            // three launches, which wait for nothing and overlap freely.
+            if ((1 + per1) * nbv <= ctx->eval_slots[ti][gi] && claim_eval_all(ctx)) {
                 if (ctx->xcd_local < 0) ctx->xcd_local = probe_xcd_local(ctx->stream) ? 1 : 0;
                 one = ctx->xcd_local == 1;
             }

@@ -27,7 +27,7 @@ def _same_draws(ref, got, rtol=1e-7, atol=1e-14):
     assert np.array_equal(ref.events, got.events)
     assert np.array_equal(ref.hmc["is_accepted"], got.hmc["is_accepted"])
     np.testing.assert_allclose(got.theta, ref.theta, rtol=rtol, atol=atol)
-    np.testing.assert_allclose(got.hmc["target_log_prob"], ref.hmc["target_log_prob"], rtol=1e-10, atol=0.0)
+    np.testing.assert_allclose(got.hmc["target_log_prob"], ref.hmc["target_log_prob"], rtol=max(1e-10, 1e-3 * rtol), atol=0.0)
     np.testing.assert_allclose(got.hmc["step_size"], ref.hmc["step_size"], rtol=max(rtol, 1e-6), atol=0.0)
     for mk in ref.moves:
         assert np.array_equal(ref.moves[mk]["is_accepted"], got.moves[mk]["is_accepted"]), mk
@@ -150,17 +150,20 @@ def test_sampler_recovers_from_a_time_out_by_itself(api, name, B):
                 tail2 = s.sample(burst)
                 runs[disturb] = (got, tail, tail2, list(s.recoveries), s.launch_form(), s.get_state())
     ref, got = runs[False], runs[True]
+    # (the micro case's trajectories amplify a last-bit difference between two launch forms by ~1e8 over the 32 sweeps -- the
+    # integer draws and the events, compared exactly, are what shows that it is the same chain)
+    tol = dict(rtol=1e-7, atol=1e-14) if name == "uk380" else dict(rtol=1e-3, atol=1e-6)
     assert not ref[3] and len(got[3]) == 2, got[3]
     assert got[3][0]["failed_form"] == ("chunk", "paired") and got[3][0]["rerun_form"] == ("chunk-launch", "paired-launch")
     assert sorted(got[0]) == list(range(nb))
     from types import SimpleNamespace
     for i in range(nb):
         a, b = (SimpleNamespace(theta=x[0], events=x[1], hmc=x[2], moves=x[3]) for x in (ref[0][i], got[0][i]))
-        _same_draws(a, b)
-    _same_draws(ref[1], got[1])
-    _same_draws(ref[2], got[2])
+        _same_draws(a, b, **tol)
+    _same_draws(ref[1], got[1], **tol)
+    _same_draws(ref[2], got[2], **tol)
     assert np.array_equal(ref[5][1], got[5][1])
-    np.testing.assert_allclose(got[5][2], ref[5][2], rtol=1e-10, atol=0.0)
+    np.testing.assert_allclose(got[5][2], ref[5][2], rtol=max(1e-10, 1e-3 * tol["rtol"]), atol=0.0)
 
 
 def test_two_samplers_started_together_on_one_gpu_both_deliver_their_solo_draws(api):

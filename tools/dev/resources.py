@@ -1,23 +1,66 @@
 #!/usr/bin/env python3
-"""Per-kernel register / scratch / LDS use from `hipcc -Rpass-analysis=kernel-resource-usage` output.
-usage: hipcc ... -Rpass-analysis=kernel-resource-usage ... 2> res.txt; python tools/dev/resources.py res.txt [filter]"""
+"""Per-kernel register / scratch / LDS use from `hipcc -Rpass-analysis=kernel-resource-usage` remarks.
+
+    python tools/dev/resources.py remarks.txt [filter]              # table
+    python tools/dev/resources.py --json out.json remarks.txt       # {kernel: {...}} (what __graft_entry__.build() keeps
+                                                                    #  next to the library as kernel_resources.json)
+`parse(text)` is what the build and tests/test_resources.py use."""
+import json
 import re
-import shutil
-import subprocess
 import sys
 
-txt = open(sys.argv[1]).read()
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
-filt = shutil.which("c++filt")
-for b in re.split(r'remark: [^\n]*Function Name: ', txt)[1:]:
-    name = b.split('\n')[0].strip()
 
-    def g(k):
-        m = re.search(k + r': (\d+)', b)
-        return int(m.group(1)) if m else -1
-    if filt:
-        name = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip()
-    name = re.sub(r'\(.*', '', name).replace('void seir::', '')
-    if flt in name:
-        print(f"{name:64s} sgpr={g('SGPRs'):3d} vgpr={g('VGPRs'):3d} agpr={g('AGPRs'):3d} scratch={g('ScratchSize .bytes/lane.'):4d} "
-              f"occ={g('Occupancy .waves/SIMD.')} lds={g('LDS Size .bytes/block.')}")
+def demangle(name):
+    """`_ZN4seir6k_leapILi1ELi6ELi1ELi6EEEv...` -> `k_leap<1,6,1,6>` (the library's kernels only take integer and bool
+    template arguments; anything else is returned as it is)."""
+    m = re.match(r"_ZN4seir(\d+)", name)
+    if not m:
+        m = re.match(r"_Z(\d+)", name)
+        if not m:
+            return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    if not rest.startswith("I"):
+        return base
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        a = re.match(r"L([ibjlmxy])(n?)(\d+)E", rest[i:])
+        if not a:
+            return base + "<?>"
+        v = ("-" if a.group(2) else "") + a.group(3)
+        args.append({"b": {"0": "false", "1": "true"}.get(v, v)}.get(a.group(1), v) if a.group(1) == "b" else v)
+        i += a.end()
+    return f"{base}<{','.join(args)}>"
+
+
+FIELDS = {"sgpr": "TotalSGPRs", "vgpr": "VGPRs", "agpr": "AGPRs", "scratch_bytes_per_lane": r"ScratchSize \[bytes/lane\]",
+          "occupancy_waves_per_simd": r"Occupancy \[waves/SIMD\]", "sgpr_spill": "SGPRs Spill", "vgpr_spill": "VGPRs Spill",
+          "lds_bytes_per_block": r"LDS Size \[bytes/block\]"}
+
+
+def parse(text):
+    out = {}
+    for blk in re.split(r"remark: [^\n]*Function Name: ", text)[1:]:
+        name = demangle(blk.split()[0])
+        ent = {}
+        for key, pat in FIELDS.items():
+            m = re.search(r"remark:\s+" + pat + r": (\d+)", blk)
+            ent[key] = int(m.group(1)) if m else None
+        out[name] = ent
+    return out
+
+
+if __name__ == "__main__":
+    argv = sys.argv[1:]
+    if argv and argv[0] == "--json":
+        res = parse(open(argv[2]).read())
+        json.dump(res, open(argv[1], "w"), indent=1, sort_keys=True)
+        print(f"{len(res)} kernels -> {argv[1]}")
+    else:
+        res = parse(open(argv[0]).read())
+        flt = argv[1] if len(argv) > 1 else ""
+        for name, e in sorted(res.items()):
+            if flt in name:
+                print(f"{name:40s} sgpr={e['sgpr']:3d} vgpr={e['vgpr']:3d} agpr={e['agpr']:3d} scratch={e['scratch_bytes_per_lane']:4d} "
+                      f"spill(s/v)={e['sgpr_spill']}/{e['vgpr_spill']} occ={e['occupancy_waves_per_simd']} lds={e['lds_bytes_per_block']}")
