@@ -126,6 +126,8 @@ def _load():
     fn("H5Fget_access_plist", hid_t, hid_t)
     fn("H5Pget_driver", hid_t, hid_t)
     fn("H5Gcreate2", hid_t, hid_t, c_char_p, hid_t, hid_t, hid_t)
+    fn("H5Lget_name_by_idx", ctypes.c_ssize_t, hid_t, c_char_p, c_int, c_int, hsize_t, c_char_p, c_size_t, hid_t)
+    fn("H5Gget_info_by_name", c_int, hid_t, c_char_p, c_void_p, hid_t)
 
     class _GInfo(ctypes.Structure):
         _fields_ = [("storage_type", c_int), ("nlinks", hsize_t), ("max_corder", ctypes.c_int64), ("mounted", c_uint)]
@@ -330,8 +332,21 @@ class File:
         if ok:
             fapl = lib.H5Fget_access_plist(self._f)
             if fapl >= 0:
-                lib.H5FD_sec2_init.restype = hid_t            # what the H5FD_SEC2 macro expands to
-                sec2 = lib.H5FD_sec2_init()
+                # the id of the plain POSIX ("sec2") driver: H5FD_sec2_init() is what the H5FD_SEC2 macro expands to up to
+                # HDF5 1.14; the development branch makes it an id global instead.  A library that exports neither: no raw
+                # writes, H5Dwrite serves the dataset like any other.
+                sec2 = -1
+                try:
+                    init = lib.H5FD_sec2_init
+                    init.restype = hid_t
+                    sec2 = init()
+                except AttributeError:
+                    for sym in ("H5FD_SEC2_id_g", "H5FD_SEC2_g"):
+                        try:
+                            sec2 = hid_t.in_dll(lib, sym).value
+                            break
+                        except ValueError:
+                            continue
                 ok = sec2 > 0 and lib.H5Pget_driver(fapl) == sec2
                 lib.H5Pclose(fapl)
             else:
@@ -571,18 +586,63 @@ class File:
         self._lib.H5Gclose(g)
         return int(info.nlinks)
 
+    def _links(self, group):
+        """Names of the links of a group, in name order."""
+        lib = self._lib
+        info = lib._GInfo()
+        if lib.H5Gget_info_by_name(self._f, group.encode(), ctypes.byref(info), H5P_DEFAULT) < 0:
+            return []
+        out = []
+        for i in range(int(info.nlinks)):
+            n = lib.H5Lget_name_by_idx(self._f, group.encode(), 0, 0, i, None, 0, H5P_DEFAULT)     # H5_INDEX_NAME, H5_ITER_INC
+            if n < 0:
+                continue
+            buf = ctypes.create_string_buffer(int(n) + 1)
+            lib.H5Lget_name_by_idx(self._f, group.encode(), 0, 0, i, buf, int(n) + 1, H5P_DEFAULT)
+            out.append(buf.value.decode())
+        return out
+
+    def _read_int_attr(self, obj, attr):
+        lib = self._lib
+        if lib.H5Aexists_by_name(self._f, obj.encode(), attr.encode(), H5P_DEFAULT) <= 0:
+            return None
+        a = lib.H5Aopen_by_name(self._f, obj.encode(), attr.encode(), H5P_DEFAULT, H5P_DEFAULT)
+        if a < 0:
+            return None
+        v = ctypes.c_int32(-1)
+        rc = lib.H5Aread(a, _ids["H5T_NATIVE_INT32_g"], ctypes.byref(v))
+        lib.H5Aclose(a)
+        return int(v.value) if rc >= 0 else None
+
+    def next_netcdf_dimid(self):
+        """Dimension ids are global to a netCDF-4 file and netCDF-C expects them dense: the next one is one more than the
+        largest `_Netcdf4Dimid` any dataset of the root group or of its groups carries (0 in a file without dimensions)."""
+        top = -1
+        for name in self._links("/"):
+            paths = ["/" + name] + ["/" + name + "/" + sub for sub in self._links("/" + name)]
+            for path in paths:
+                v = self._read_int_attr(path, "_Netcdf4Dimid")
+                if v is not None:
+                    top = max(top, v)
+        return top + 1
+
     def write_netcdf_group(self, group, coords, variables):
-        """One netCDF-4 group as `xarray.Dataset.to_netcdf(group=...)` lays it out.
+        """One netCDF-4 group laid out as the netCDF-4 format specifies (and `xarray.Dataset.to_netcdf(group=...)` produces).
 
         coords: ordered {dimension name: coordinate values} -- int arrays, a list of str (variable-length strings) or
         datetime64[D] (CF: int64 days since the first date, with `units` / `calendar`); variables: {name: (dims, array)}.
-        Every dimension is an HDF5 dimension scale (CLASS / NAME by H5DSset_scale, `_Netcdf4Dimid` unique in the file)
-        holding its coordinate, attached to every axis of the variables that use it."""
+        Every dimension is an HDF5 dimension scale (CLASS / NAME by H5DSset_scale) holding its coordinate, with a
+        `_Netcdf4Dimid` that continues the file's numbering (ids are global to the file and contiguous: 0, 1, 2, ...
+        over all groups), attached to every axis of the variables that use it; a variable of more than one dimension also
+        carries `_Netcdf4Coordinates`, the ids of its dimensions in order, as netCDF-C writes it.  The layout is checked by
+        reading it back with h5py (tests/test_hostio.py); no netCDF-C / xarray reader exists in this image, so that a file
+        opens in them is what the format description promises, not something that was run."""
         hl = _load_hl()
         if hl is None:
             raise OSError("libhdf5_hl (dimension scales) not found: cannot write a netCDF-4 group")
         g = "/" + group.strip("/")
-        base = 16 * self.num_root_links()                      # dimension ids are global to a netCDF-4 file
+        base = self.next_netcdf_dimid()
+        dimid = {}
         for i, (dim, values) in enumerate(coords.items()):
             path = f"{g}/{dim}"
             v = np.asarray(values)
@@ -600,6 +660,7 @@ class File:
                 self.create_dataset(path, v.shape, np.int64 if v.dtype.kind in "iu" else np.float64)
                 self.write(path, v)
             _check(hl.H5DSset_scale(self._open(path), dim.encode()), f"dimension scale {path!r}")
+            dimid[dim] = base + i
             self.write_attr(path, "_Netcdf4Dimid", np.int32(base + i))
         for name, (dims, array) in variables.items():
             a = np.asarray(array, dtype=np.float64)
@@ -611,6 +672,8 @@ class File:
             self.write_attr(path, "_FillValue", np.array([np.nan]))
             for k, dm in enumerate(dims):
                 _check(hl.H5DSattach_scale(self._open(path), self._open(f"{g}/{dm}"), k), f"attach {dm!r} to {path!r}")
+            if len(dims) > 1:
+                self.write_attr(path, "_Netcdf4Coordinates", np.array([dimid[dm] for dm in dims], dtype=np.int32))
 
     def read_str_attr(self, obj, attr):
         """String attribute `attr` of object `obj`, or None."""

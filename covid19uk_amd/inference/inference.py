@@ -378,6 +378,9 @@ def mcmc(data_file, output_file, config, seed=0, num_chains=1, device=None, pool
                 dist.init_process_group(backend)
     model = SeirModel(cov, initial_state, max_chains=B, device=lay["device"])
     hmc_form, moves_form = launch_forms(lay, device, hmc, moves)
+    if (hmc_form, moves_form) != ("chunk", "paired") and hmc == "auto" and moves == "auto":
+        print(f"[rank {lay['rank']}] ranks of this job share device {lay['device']}: launch forms {hmc_form!r}, {moves_form!r} "
+              "(one launch per leapfrog step / per pair of event updates)", file=sys.stderr, flush=True)
     sampler = ChainSampler(model, cfg, B, seed=seed, t_range=(max(T - 21, 0), T),
                            num_leapfrog_steps=hmc_kernel_kwargs_default()["num_leapfrog_steps"],
                            trace_capacity=cap, record_events=trace_events_dtype(cases, events_dtype),

@@ -76,9 +76,13 @@ def test_two_rank_job_equals_one_process_with_all_chains(tmp_path):
     env = dict(os.environ, PYTHONPATH=H.ROOT)
     one = tmp_path / "one"
     one.mkdir()
-    r = subprocess.run(base + ["--chains", "4", "-o", str(one / "posterior.hd5"), data], cwd=H.ROOT, env=env,
+    # (the two ranks below are given the same --device: mcmc() then runs the per-step launch forms, two persistent
+    # whole-chip launches cannot share a GPU; the reference run is told to use the same forms -- same code, same bits)
+    r = subprocess.run(base + ["--chains", "4", "--hmc", "chunk-launch", "--moves", "paired-launch",
+                               "-o", str(one / "posterior.hd5"), data], cwd=H.ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "share" not in r.stderr
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -94,6 +98,7 @@ def test_two_rank_job_equals_one_process_with_all_chains(tmp_path):
         out, err = p.communicate(timeout=900)
         assert p.returncode == 0, err[-2000:]
         assert "Pooled step size" in err
+        assert "ranks of this job share device 0" in err, err[-2000:]
     n = 1825 + 80
     for c in range(4):
         with hdf5io.File(str(one / f"posterior_chain{c}.hd5"), "r") as fa, \

@@ -149,7 +149,11 @@ q = f["posterior_predictive"]
 assert [q["R_it"].dims[i][0].name.split("/")[-1] for i in range(3)] == ["iteration", "time", "location"]
 assert [q["R_t"].dims[i][0].name.split("/")[-1] for i in range(2)] == ["iteration", "time"]
 ids = [int(x.attrs["_Netcdf4Dimid"]) for grp in (g, q) for x in grp.values() if h5py.h5ds.is_scale(x.id)]
-assert len(set(ids)) == len(ids), ids
+assert sorted(ids) == list(range(8)), ids                 # global to the file and dense: 5 of the first group, then 3
+by_name = {x.name.split("/")[-1]: int(x.attrs["_Netcdf4Dimid"]) for x in g.values() if h5py.h5ds.is_scale(x.id)}
+assert list(v.attrs["_Netcdf4Coordinates"]) == [by_name[n] for n in ("iteration", "location", "time", "event")]
+qn = {x.name.split("/")[-1]: int(x.attrs["_Netcdf4Dimid"]) for x in q.values() if h5py.h5ds.is_scale(x.id)}
+assert list(q["R_t"].attrs["_Netcdf4Coordinates"]) == [qn["iteration"], qn["time"]]
 assert np.isnan(v.attrs["_FillValue"][0])
 print("ok")
 """, p, str(tmp_path / "ev.npy"))
@@ -349,3 +353,20 @@ def test_dispersed_start_is_keyed_by_global_chain_id():
     assert not a[0].any() and a[1:].any(axis=1).all()
     np.testing.assert_array_equal(a[2:], b)
     assert not np.array_equal(a[1], inf.dispersed_start(7, [1], 0.1, seed=4)[0])
+
+
+def test_launch_forms_follow_the_job_layout():
+    """mcmc() runs the persistent whole-chip launches only where a rank has its GPU to itself: several ranks given the
+    same --device (torchrun hands every rank the same command line) get one launch per leapfrog step / per pair."""
+    from covid19uk_amd.inference import inference as inf
+    solo = inf.job_layout(2, None, env={})
+    assert inf.launch_forms(solo, None, env={}) == ("chunk", "paired")
+    assert inf.launch_forms(solo, 0, env={}) == ("chunk", "paired")                    # one process, explicit device
+    env = {"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2"}
+    lay = inf.job_layout(2, None, env=env)
+    assert inf.launch_forms(lay, None, env=env) == ("chunk", "paired")                 # one GPU per rank (LOCAL_RANK)
+    lay = inf.job_layout(2, 0, env=env)
+    assert inf.launch_forms(lay, 0, env=env) == ("chunk-launch", "paired-launch")      # both ranks on device 0
+    assert inf.launch_forms(lay, 0, hmc="chunk", moves="auto", env=env) == ("chunk", "paired-launch")   # explicit wins
+    env1 = dict(env, LOCAL_WORLD_SIZE="1")                                               # two nodes, one rank each
+    assert inf.launch_forms(inf.job_layout(2, 0, env=env1), 0, env=env1) == ("chunk", "paired")
