@@ -82,7 +82,7 @@ def test_two_rank_job_equals_one_process_with_all_chains(tmp_path):
                                "-o", str(one / "posterior.hd5"), data], cwd=H.ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "share" not in r.stderr
+    assert "ranks of this job share" not in r.stderr
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

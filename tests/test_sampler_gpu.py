@@ -225,6 +225,17 @@ def test_sampler_matches_oracle_draw_by_draw_at_uk380(api):
         assert (rows >= 64).any() and (rows >= 320).any()
     assert tr.hmc["is_accepted"].any()
     assert any(tr.moves[key]["is_accepted"].any() for key in tr.moves)
+    # BASELINE.json's third configuration exactly: ONE chain of UK-380 on the GPU (the layout of eight with seven chains
+    # absent: a single XCD carries the sweep), in the default launch forms -- and in both tile shapes of the persistent
+    # leapfrog launch -- against the first oracle chain
+    for rows_ in (0, 32):
+        with SeirModel(case["cov"], case["init"], max_chains=1) as model:
+            with ChainSampler(model, CFG_REF, 1, seed=21, first_chain_id=3, trace_capacity=n, leap_rows=rows_) as s:
+                s.set_state(u[:1], ev[:1])
+                s.set_kernel(step_size=eps)
+                tr1 = s.sample(n)
+                assert s.launch_form() == ("chunk", "paired") and not s.recoveries
+        _compare(tr1, oracles[:1], n, 1, CFG_REF)
 
 
 def test_adaptation_windows_match_oracle(api):
@@ -672,10 +683,19 @@ def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
     ev = np.stack([case["events"]] * B)
     cfg = CFG_REF if name == "uk380" else CFG_SMALL
     out = {}
-    for mode, skew in (("chunk-split", 0), ("chunk-launch", 0), ("chunk-leap", 0), ("chunk-stage", 0), ("chunk", 0), ("chunk", 3)):
+    rows_of = {}
+    for mode, skew in (("chunk-split", 0), ("chunk-launch", 0), ("chunk-leap", 0), ("chunk-stage", 0), ("chunk", 0), ("chunk", 3),
+                       ("chunk/32", 0), ("chunk-stage/32", 0)):
+        # "/32": the 32-row tile shape of the persistent launch where the default is the 24-row one (UK-380)
+        mode, _, rows_ = mode.partition("/")
+        rows_of[(mode, skew)] = rows_
+        if rows_:
+            if name != "uk380":
+                continue
+            skew = 32                                        # (key only)
         with api[0](case["cov"], case["init"], max_chains=B) as model:
-            model.set_option(debug_skew=skew)
-            with api[1](model, cfg, B, seed=13, trace_capacity=3, hmc=mode) as s:
+            model.set_option(debug_skew=skew if skew != 32 else 0)
+            with api[1](model, cfg, B, seed=13, trace_capacity=3, hmc=mode, leap_rows=int(rows_ or 0)) as s:
                 if mode != "chunk-split" and not s.xcd_local():
                     pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the fused forms are not used")
                 s.set_state(u, ev)
@@ -693,6 +713,11 @@ def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
         got, got_state = out[(mode, 0)]
         _same_chain_up_to_rounding(ref, got)
         np.testing.assert_allclose(got_state[2], ref_state[2], rtol=1e-11, atol=0.0)
+    for key in (("chunk", 32), ("chunk-stage", 32)):             # ... in the other tile shape too
+        if key in out:
+            got, got_state = out[key]
+            _same_chain_up_to_rounding(ref, got)
+            np.testing.assert_allclose(got_state[2], ref_state[2], rtol=1e-11, atol=0.0)
     base, base_state = out[("chunk", 0)]                        # ... and their own bits under workgroup skew
     got, got_state = out[("chunk", 3)]
     assert np.array_equal(base.theta, got.theta) and np.array_equal(base.events, got.events)
