@@ -2055,14 +2055,8 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
     const int role = role_in, b = b_in;
     if (d.nlive > 0 && bz >= d.nlive) return;
     debug_skew(d);
-    // A role shares its SIMDs with tile waves (three of them per SIMD in the 24-row form) that are bound by instruction issue
-    // and OLDER than it: issue goes to the oldest wave first, and the role's loads and address arithmetic ahead of its wait
-    // were served in the gaps the tiles left -- an M-chunk role reached its wait 5.2 us into a step whose tiles were all in
-    // at 3.8 (tools/dev/leap_timeline.py).  The roles are the serial part of a step: they go first.
-#ifndef LEAP_ROLE_PRIO
-#define LEAP_ROLE_PRIO 3
-#endif
-    __builtin_amdgcn_s_setprio(LEAP_ROLE_PRIO);
+    // (Raising the role waves' priority over the tile waves they share SIMDs with -- s_setprio 3, also dropped to 0 while a
+    // role only polls -- was measured and changes nothing: 0.334 - 0.335 ms per sweep in all three variants.)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane_w = (int)(threadIdx.x & 63);
     const int nsh = min(LEAP_NSH, nwg);
