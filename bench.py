@@ -445,6 +445,36 @@ def main():
     except Exception as e:                                  # an extra, never the reason a bench line is missing
         evals["three_contexts_error"] = str(e)
 
+    # BASELINE's "log_prob evals/sec" names no batch size: the same call with more chains per batch on ONE context (its own
+    # context per size; the one-launch form serves 8 and 16 chains, the three-launch form the larger batches, where the
+    # wide kernels fill the chip by themselves)
+    try:
+        if syn:
+            raise RuntimeError("skipped at SYN-2048")
+        by_batch = {}
+        for Bx in (16, 32, 64):
+            with SeirModel(cov, init, max_chains=Bx, device=local) as mb_:
+                ub_ = torch.tensor(synth.jitter_params(u_true, Bx, scale=0.002, seed=7, T=cov.T), device=dev)
+                eb_ = torch.tensor(np.stack([events] * Bx), device=dev)
+                lb_ = torch.empty(Bx, dtype=torch.float64, device=dev)
+                gb_ = torch.empty(Bx, P, dtype=torch.float64, device=dev)
+                ent_ = {}
+                for name, g in (("value", None), ("value_and_grad", gb_)):
+                    for _ in range(3):
+                        mb_.log_prob_dev(ub_, eb_, lb_, g)
+                    mb_.sync()
+                    mb_.timer_start()
+                    for _ in range(30):
+                        mb_.log_prob_dev(ub_, eb_, lb_, g)
+                    ms_b = mb_.timer_stop()
+                    ent_[name] = Bx * 30 / (ms_b * 1e-3)
+                    ent_[name + "_us_per_batch"] = 1e3 * ms_b / 30
+                by_batch[str(Bx)] = ent_
+                del ub_, eb_, lb_, gb_
+        evals["by_chains_per_batch_one_context"] = by_batch
+    except Exception as e:                                  # an extra, never the reason a bench line is missing
+        evals["by_batch_error"] = str(e)
+
     # the stateless evaluation (what the reference calls 37x per draw) against ITS bound: the larger of the
     # HBM time of the algorithmic bytes and the fp64 matrix time of the mobility contraction 2 M^2 T per chain
     t_hbm = alg_bytes / (HBM_PEAK_GBPS * 1e9)
