@@ -687,7 +687,7 @@ def main():
             out["roofline_sweep_kernel"] = out["roofline"]
             out["roofline"] = contraction["f32" if f32 else "f64"]
             out["contraction"] = contraction
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:              # (the contract: rank 0, N = 1 only)
             out["cpu_baseline"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps or (2 if syn else 0), a.seed)
             if not syn:       # one core would need minutes per sweep at this size
                 out["cpu_baseline_1core"] = cpu_baseline(cov, init, events, u0[0], a.cpu_baseline_sweeps, a.seed, cores=1)
