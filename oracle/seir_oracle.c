@@ -34,17 +34,7 @@
 #define EPS64 2.220446049250313e-16
 #define LOG_2PI 1.8378770664093453
 
-typedef struct {
-    int M, T;
-    const double *Cstar;      /* [M*M] row-major */
-    const double *N;          /* [M] */
-    const double *W;          /* [T] */
-    const double *weekday_c;  /* [T] */
-    const double *log_area_c; /* [M] */
-    const double *car_Q;      /* [M*M] */
-    double car_half_logdet;
-    const double *init_state; /* [M*4] */
-} oracle_consts;
+#include "seir_oracle.h"
 
 static double lgam(double x) { int s; return lgamma_r(x, &s); }
 

@@ -8,6 +8,7 @@ import pytest
 
 from oracle import mcmc_oracle as mo
 from oracle import seir_oracle as so
+from covid19uk_amd import synth
 from tests import helpers as H
 
 CFG = dict(dmax=6, nmax=5, m=2, occult_nmax=4, num_event_time_updates=2)
@@ -186,3 +187,74 @@ def test_dual_averaging_moves_step_size_toward_target():
         acc.append(ch.sweep_once()["hmc"]["is_accepted"])
     assert ch.eps < 0.5
     assert np.mean(acc[20:]) > 0.3
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle/mcmc_oracle.c (the sweep in plain C: what bench.py times on the host cores) against oracle/mcmc_oracle.py
+# ---------------------------------------------------------------------------------------------
+def _same_sweep(ra, rb, where):
+    assert ra["hmc"]["is_accepted"] == rb["hmc"]["is_accepted"], where
+    lp = ra["hmc"]["target_log_prob"]
+    assert abs(rb["hmc"]["target_log_prob"] - lp) <= 1e-9 * abs(lp), where
+    assert abs(rb["hmc"]["step_size"] - ra["hmc"]["step_size"]) <= 1e-7 * ra["hmc"]["step_size"], where
+    for key in ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I"):
+        assert np.array_equal(ra[key]["proposed_delta"], rb[key]["proposed_delta"]), (where, key)
+        assert ra[key]["is_accepted"] == rb[key]["is_accepted"], (where, key)
+        qa, qb = ra[key]["log_q_ratio"], rb[key]["log_q_ratio"]
+        assert qa == qb or abs(qa - qb) < 1e-12, (where, key)
+    assert np.array_equal(ra["events"], rb["events"]), where
+    np.testing.assert_allclose(rb["theta"], ra["theta"], rtol=1e-7, atol=1e-12, err_msg=str(where))
+
+
+@pytest.mark.parametrize("name,cfg,eps,n", [("micro_5x24", dict(dmax=8, nmax=6, m=2, occult_nmax=5, num_event_time_updates=3), 0.002, 10),
+                                            ("ni11", dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 0.002, 4),
+                                            ("micro_2x2", dict(dmax=3, nmax=1, m=1, occult_nmax=1, num_event_time_updates=1), 0.002, 8),
+                                            ("micro_17x70", dict(dmax=8, nmax=6, m=4, occult_nmax=5, num_event_time_updates=2), 0.0004, 4)])
+def test_c_sampler_follows_the_python_oracle_draw_by_draw(name, cfg, eps, n):
+    """Same Philox stream, same proposals, same decisions; the Box-Muller normals differ in the last bit (NumPy's
+    vectorised log / sin / cos are not glibc's), so continuous quantities agree to rounding."""
+    from oracle import c_binding as cb
+    case = H.build_case(name, 3, alpha_t_sd=0.005)
+    u = synth.jitter_params(case["u"], 1, scale=0.05, seed=3, T=case["k"].T)[0]
+    a = mo.OracleChain(case["k"], cfg, u, case["events"], seed=77, chain_id=5)
+    b = cb.COracleChain(case["k"], cfg, u, case["events"], seed=77, chain_id=5)
+    a.eps = b.eps = eps
+    assert abs(a.logp - b.logp) <= 1e-10 * abs(a.logp)
+    for i in range(n):
+        _same_sweep(a.sweep_once(), b.sweep_once(), (name, i))
+    assert a.n_evals == b.n_evals                     # a full evaluation per proposal, as the reference
+
+
+def test_c_sampler_adaptation_windows_and_disabled_kernels():
+    from oracle import c_binding as cb
+    cfg = dict(dmax=8, nmax=6, m=2, occult_nmax=5, num_event_time_updates=2)
+    case = H.build_case("micro_5x24", 9, alpha_t_sd=0.005)
+    k = case["k"]
+    u = synth.jitter_params(case["u"], 1, scale=0.05, seed=4, T=k.T)[0]
+    a = mo.OracleChain(k, cfg, u, case["events"], seed=5, chain_id=2)
+    b = cb.COracleChain(k, cfg, u, case["events"], seed=5, chain_id=2)
+    a.eps = b.eps = 0.004
+    for ch in (a, b):
+        ch.set_adaptation(adapt_step=True, num_adaptation_steps=6)
+    for i in range(8):                                # runs past the window: the averaged step size takes over
+        _same_sweep(a.sweep_once(), b.sweep_once(), ("fast", i))
+    rv = (5.0, np.full(k.P, 0.1), np.full(k.P, 0.5))
+    for ch in (a, b):
+        ch.set_adaptation(adapt_step=True, adapt_mass=True, num_adaptation_steps=5, running_variance=rv)
+    for i in range(6):
+        _same_sweep(a.sweep_once(), b.sweep_once(), ("slow", i))
+    np.testing.assert_allclose(b.var, a.var, rtol=1e-7)
+    # sub-kernels that draw but never accept
+    dis = ("hmc", "occult/E->I")
+    a2 = mo.OracleChain(k, cfg, u, case["events"], seed=5, chain_id=2, disable=dis)
+    b2 = cb.COracleChain(k, cfg, u, case["events"], seed=5, chain_id=2, disable=dis)
+    for i in range(5):
+        ra, rb = a2.sweep_once(), b2.sweep_once()
+        assert not rb["hmc"]["is_accepted"] and not rb["occult/E->I"]["is_accepted"]
+        for key in ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I"):
+            assert np.array_equal(ra[key]["proposed_delta"], rb[key]["proposed_delta"]) and ra[key]["is_accepted"] == rb[key]["is_accepted"]
+        assert np.array_equal(ra["events"], rb["events"])
+    b2.run(3)                                         # the timed form: nothing but C in the loop
+    for _ in range(3):
+        a2.sweep_once()
+    assert np.array_equal(a2.events, b2.events)
