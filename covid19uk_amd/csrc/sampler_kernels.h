@@ -75,6 +75,8 @@ __device__ __forceinline__ void move_copy(Move *dst, const Move *src, int t0) {
 }
 
 constexpr int TAIL_STRIDE = 16;       // 64-bit words between two chains' ticket counters
+constexpr int ROLE_SLOTS = 64;        // chunk roles of a chain that leave parts of the trajectory's ends (k0part, finpart): T-chunks +
+                                      // M-chunks, one lane each when a role adds them up (SYN-2048 has 12 + 32)
 constexpr int NMVTR = 2 + 4 * MMAX;   // is_accepted, target_log_prob, m[], t[], delta_t[], x_star[]
 
 struct PairNote;
@@ -91,7 +93,7 @@ struct Chains {
                                                          // from (band tokens, k_se_chunk's tile flag): the workgroup went on without its data
     int late_fatal;
                                                          //     (+ k_se_chunk: chunk roles that gave up waiting for the chain's tiles)
-    double *finpart;                                     // [B][32][4] k_leap with the trajectory's end folded in: per role, its parts of the
+    double *finpart;                                     // [B][ROLE_SLOTS][4] k_leap with the trajectory's end folded in: per role, its parts of the
                                                          //     end point's kinetic energy and log-probability (and, by T-chunk 0, the
                                                          //     running-variance count), for the accept test every role then makes
     unsigned *pbar;                                      // [B][PBAR_STRIDE] k_move_pairs: arrivals of the chain's workgroups at the end of a
@@ -104,7 +106,7 @@ struct Chains {
                                                          //     then [B][TAIL_FLAG_STRIDE]: the count at which the chain's last tile raised
                                                          //     the flag the roles poll
     unsigned long long *leap;                            // [B][LEAP_CH] k_leap's counters and flags (see there), a chain's in its own 8 KB
-    double *k0part;                                      // [B][32] k_leap with the trajectory's first step folded in: the roles' parts of
+    double *k0part;                                      // [B][ROLE_SLOTS] k_leap with the trajectory's first step folded in: the roles' parts of
                                                          //         the start point's kinetic energy
     double *irl0;                                        // [B] ... and the I->R term of its log-probability
     unsigned long long *leap_st;                         // [B][16][8] developer timeline of k_leap (LEAP_STAMPS builds only)
@@ -813,18 +815,46 @@ __global__ __launch_bounds__(HB) void k_hmc_step(Dims d, Consts c, Work w, Sampl
 //            small-M form (the M-chunks sum the row partials of ALL rows themselves) rows kk of a lane by waves 1,2,3,1,2,3,1,2.
 template <int NC> struct RoleGather {                           // offsets (doubles) into the role's LDS block
     static constexpr int C = 0, BS = 4 * WAVE, AS = BS + NC * WAVE;                              // T-chunk
-    static constexpr int X = 0, PS = NC * WAVE, RL = PS + WAVE, RS = RL + WAVE, ACC = RS + WAVE, SX = ACC + 8 * WAVE;   // M-chunk
-    static constexpr int SIZE = (4 + 2 * NC) * WAVE > (NC + 3 + 16) * WAVE ? (4 + 2 * NC) * WAVE : (NC + 3 + 16) * WAVE;
+    static constexpr int X = 0, PS = NC * WAVE, RL = PS + WAVE, RS = RL + WAVE, ACC = RS + WAVE, SX = ACC + 8 * WAVE,
+                         QS = SX + 8 * WAVE;                                                     // M-chunk
+    static constexpr int SIZE = (4 + 2 * NC) * WAVE > (NC + 3 + 17) * WAVE ? (4 + 2 * NC) * WAVE : (NC + 3 + 17) * WAVE;
 };
 __device__ __forceinline__ int role_gather_row_wave(int kk) { return 1 + kk % 3; }     // rows of a lane by waves 1, 2, 3, 1, 2, 3, 1, 2
 // ... and, before the wait for the tiles (but after the previous step's roles are done), the rows' spatial effects at the
 // current position for the same rows: 8 more loads past the L1 that wave 0 no longer issues on its way to the wait
+// ... and the CAR term (Q s)_m of the chunk's own rows at the current position, by the helper wave with the fewest rows to
+// gather (wave 3): two dependent round trips (the row's columns, then the spatial effects there) that the role's own wave made
+// on its way to the wait -- it reached it 1.3 us after the tiles were in.  Same operands in the same order: the same bits.
+__device__ __forceinline__ bool role_qs_by_helper(const Consts &c) { return c.qw > 0 && c.qw <= 8; }
 template <int NTC>
-__device__ __forceinline__ void role_pregather(const Dims &d, const double *spr, int bx, int wv, int lane, double *g) {
+__device__ __forceinline__ void role_pregather(const Dims &d, const Consts &c, const double *spr, int bx, int wv, int lane, double *g) {
     constexpr int NC = NTC > 0 ? NTC : CT_MAXC;
     using G = RoleGather<NC>;
     const int ntc = NTC > 0 ? NTC : d.ntc;
-    if (bx < ntc || d.chunked != 1) return;
+    if (bx < ntc) return;
+    if (wv == 3 && role_qs_by_helper(c)) {
+        const int m = (bx - ntc) * WAVE + lane;
+        const bool own = m < d.M;
+        const int mc = own ? m : 0;
+        double qv[8]; int qc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool on = j < c.qw;
+            const size_t qi = (size_t)(on ? j : 0) * d.Mp + mc;
+            const double qv_ = c.Qell_val[qi];
+            const int qc_ = c.Qell_col[qi];
+            qv[j] = on ? qv_ : 0.0;
+            qc[j] = on ? qc_ : 0;
+        }
+        double sv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] = __hip_atomic_load(spr + qc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double Qs = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Qs += qv[j] * sv[j];
+        g[G::QS + lane] = own ? Qs : 0.0;
+    }
+    if (d.chunked != 1) return;
     const int nrow = (d.M + WAVE - 1) / WAVE;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -928,10 +958,13 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Work &w, int b,
 // PERS (k_leap: all inner steps in ONE launch): what the previous step's roles wrote -- position and momentum, the
 // global parameters, the chunk sums, the spatial effects -- was written by workgroups of this same launch too, so those
 // are read past the L1 as well (the caller makes sure every role of the previous step has finished).
-template <int NTC, bool COH, bool PERS = false, typename Wait>
+// TRAJ: the role also knows the trajectory's end points (`traj`, below): always in k_leap, and in k_se_chunk, whose launches
+// can carry the first and the last step of a trajectory as well (the stage kernels' work in chunk form: hmc_mode 6).
+template <int NTC, bool COH, bool PERS = false, bool TRAJ = PERS, typename Wait>
 __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
                                                const Chains &ch, int par, int bx, int b, Wait wait, int lane_in = -1,
-                                               unsigned long long *probe = nullptr, double *gbuf = nullptr, int traj = 0) {
+                                               unsigned long long *probe = nullptr, double *gbuf = nullptr, int traj = 0,
+                                               double eps_in = 0.0, bool tab_ready = false) {
 #ifdef LEAP_STAMPS
 #define CPROBE(k) do { asm volatile("s_nop 0" ::: "memory"); if (probe && threadIdx.x == 0) probe[(k) < 8 ? (k) : 2 * 128 + (k) - 8] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -955,7 +988,10 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
     const double *qs0 = ch.q0 + (size_t)b * d.Pp;          // the trajectory's start point (== q before the first step; nobody writes it here)
     const double *var = ch.var + (size_t)b * d.Pp;
     double *sc = w.scal + (size_t)b * NSCAL;
-    const double eps = ch.hs[(size_t)b * NHS + HS_EPS];
+    // (k_leap reads the step size once, ahead of its step loop, and fills the logarithm's table once: at the top of a role
+    // each was a memory round trip of its own -- the table's two halves one after the other -- before the role's first useful
+    // load was issued, about a microsecond of every step)
+    const double eps = PERS ? eps_in : ch.hs[(size_t)b * NHS + HS_EPS];
     // traj (k_leap with the trajectory's end points folded in): 1 = this is the FIRST step of the trajectory -- what
     // k_hmc_step<0> does in the multi-launch forms: the momentum is drawn here (same Philox slots), the kick is half a step
     // and the kinetic energy's / log-probability's parts are left for the accept test.  Everything of the start point is
@@ -965,7 +1001,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
     // 3 = the trajectory's LAST half kick (k_hmc_step<2>'s in the other forms): nothing of the position moves; the role leaves
     // its parts of the end point's kinetic energy and log-probability (Chains::finpart) for the accept test, which every
     // role makes for itself once all of them have counted in (hmc_final_apply)
-    const bool first = PERS && traj == 1, fin = PERS && traj == 3;
+    const bool first = TRAJ && traj == 1, fin = TRAJ && traj == 3;
     const double kick = (first || fin) ? 0.5 * eps : eps;
     const int oT = 6 - 1, oM = 6 + T - 1;
     const double *TS = w.TS + (size_t)b * ntile * 4;
@@ -975,8 +1011,11 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         // ------------------------------------------------------------------ T-chunk
         const int ci = bx, t = ci * WAVE + lane;
         const bool own = t >= 1 && t < T;
-        ltab[lane] = c.logtab[lane];
-        ltab[lane + WAVE] = c.logtab[lane + WAVE];
+        if (!(PERS && tab_ready)) {
+            const double2 t0_ = c.logtab[lane], t1_ = c.logtab[lane + WAVE];
+            ltab[lane] = t0_;
+            ltab[lane + WAVE] = t1_;
+        }
         const double alpha = own ? LDQ((first ? qs0 : q) + oT + t) : 0.0, v = own ? var[oT + t] : 0.0;
         const double wd_t = c.wd[t];
         const double va0 = var[5], vg0 = var[3], vg1 = var[4];
@@ -1043,11 +1082,11 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             }
             if (ci == 0 && lane == 0) ch.irl0[b] = irl;
         }
-        if (PERS && traj == 2 && ci == 0) {
+        if (TRAJ && traj == 2 && ci == 0) {
             // the step after the first: the start point's kinetic energy and log-probability from the parts the first step's
             // roles and tiles left (all of them have finished: the caller waited for that)
             const int nroles = ntc + d.Mp / WAVE;
-            const double k0 = wave_sum(lane < nroles ? LDQ(ch.k0part + (size_t)b * 32 + lane) : 0.0);
+            const double k0 = wave_sum(lane < nroles ? LDQ(ch.k0part + (size_t)b * ROLE_SLOTS + lane) : 0.0);
             double lk = 0.0;
             for (int i = lane; i < ntile; i += WAVE) lk += LDP(w.Lpart0 + (size_t)b * ntile + i);
             lk = wave_sum(lk);
@@ -1178,7 +1217,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             if (ci == 0) kin += (0.5 * vg0 * pg0n * pg0n + 0.5 * vg1 * pg1n * pg1n) + 0.5 * va0 * pa0n * pa0n;
             const double a2 = wave_sum(alpha * alpha);
             if (lane == 0) {
-                double *fpw = ch.finpart + ((size_t)b * 32 + bx) * 4;
+                double *fpw = ch.finpart + ((size_t)b * ROLE_SLOTS + bx) * 4;
                 fpw[0] = kin; fpw[1] = irl_fin; fpw[2] = a2;
                 if (ci == 0) fpw[3] = ch.hs[(size_t)b * NHS + HS_RV_N];      // (read by every role behind the hand-off; advanced by this one)
             }
@@ -1187,7 +1226,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         if (first) {
             double kin = wave_sum(own ? 0.5 * v * pm * pm : 0.0);
             if (ci == 0) kin += (0.5 * vg0 * pg0 * pg0 + 0.5 * vg1 * pg1 * pg1) + 0.5 * va0 * pa0 * pa0;
-            if (lane == 0) ch.k0part[(size_t)b * 32 + bx] = kin;
+            if (lane == 0) ch.k0part[(size_t)b * ROLE_SLOTS + bx] = kin;
         }
         const double a_new = a0n + pre + wave_incl_scan(an, lane);
         if (probe) { asm volatile("" :: "v"(a_new)); }
@@ -1216,8 +1255,11 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const int ci = bx - ntc, m = ci * WAVE + lane;
         const bool own = m < M;
         // the logarithm's table, for the softplus of the new psi and sigma_space (softplus_tab): in LDS before the wait
-        ltab[lane] = c.logtab[lane];
-        ltab[lane + WAVE] = c.logtab[lane + WAVE];
+        if (!(PERS && tab_ready)) {
+            const double2 t0_ = c.logtab[lane], t1_ = c.logtab[lane + WAVE];
+            ltab[lane] = t0_;
+            ltab[lane + WAVE] = t1_;
+        }
         // (first step of a folded trajectory: the spatial effects of the start point are q's own)
         const double *spr = first ? qs0 + oM : w.sp + ((size_t)b * 2 + par) * d.Mp;
         double *spw = w.sp + ((size_t)b * 2 + (par ^ 1)) * d.Mp;
@@ -1243,15 +1285,21 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             u0 = LDQ(gr + 0); u1 = LDQ(gr + 1); beta = LDQ(gr + 2); p0 = LDQ(gr + 6); p1 = LDQ(gr + 7); p2 = LDQ(gr + 8);
             psi = LDQ(gr + 12); sig = LDQ(gr + 13); s0 = LDQ(gr + 14); s1 = LDQ(gr + 15);
         }
+        CPROBE(5);                                          // M-chunk: entry loads issued
         double Qs = 0.0;                                   // (Q s)_m at the current position
-        if (own) {
+        const bool qs_lds = PERS && role_qs_by_helper(c);  // (k_leap: by a helper wave of the role's workgroup, through LDS)
+        if (own && !qs_lds) {
             if (c.qw > 0 && c.qw <= 8) {
                 double qv[8]; int qc[8];
+                // (clamped index + select: sixteen loads in flight; as conditional loads they were eight branches with a wait each)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool on = j < c.qw;
-                    qv[j] = on ? c.Qell_val[(size_t)j * d.Mp + m] : 0.0;
-                    qc[j] = on ? c.Qell_col[(size_t)j * d.Mp + m] : 0;
+                    const size_t qi = (size_t)(on ? j : 0) * d.Mp + m;
+                    const double qv_ = c.Qell_val[qi];
+                    const int qc_ = c.Qell_col[qi];
+                    qv[j] = on ? qv_ : 0.0;
+                    qc[j] = on ? qc_ : 0;
                 }
                 double sv[8];
 #pragma unroll
@@ -1262,6 +1310,8 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                 for (int e = c.Qrow[m]; e < c.Qrow[m + 1]; ++e) Qs += c.Qval[e] * LDQ(spr + c.Qcol[e]);
             }
         }
+        if (probe) { asm volatile("" :: "v"(Qs)); }
+        CPROBE(6);                                          // M-chunk: (Q s) formed
         const bool rows_here = d.chunked == 1;             // small M: sum_m l_m R_m, sum_m s_m R_m from the row partials
         constexpr int RPL = 8;                             // Mp <= 512: rows lane, lane+64, ...
         // (k_leap: the rows' l_m and s_m -- the previous step's -- before the wait; what waits for the tiles comes from the
@@ -1278,6 +1328,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
                 sxp[kk] = 0.0;                              // (from the helper waves, through LDS: role_pregather)
             }
         }
+        CPROBE(7);                                          // M-chunk: at the wait
         wait();
         // ---- from here on: this step's partial sums
         double R = 0.0;
@@ -1289,6 +1340,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
 #pragma unroll
             for (int j = 0; j < NC; ++j) R += gbuf[G::X + j * WAVE + lane];
             ps = gbuf[G::PS + lane]; rl = gbuf[G::RL + lane]; rs = gbuf[G::RS + lane];
+            if (qs_lds) Qs = gbuf[G::QS + lane];
             if (rows_here) {
                 const int nrow = (M + WAVE - 1) / WAVE;      // uniform
 #pragma unroll
@@ -1355,7 +1407,11 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             }
         }
         }
+        if (probe) { asm volatile("" :: "v"(ps), "v"(rl), "v"(rs), "v"(R)); }
+        CPROBE(8);                                          // M-chunk: the partial sums are in
         ps = wave_sum(ps); rl = wave_sum(rl); rs = wave_sum(rs);
+        if (probe) { asm volatile("" :: "v"(ps), "v"(rl), "v"(rs)); }
+        CPROBE(10);                                         // M-chunk: three wave sums
         const double g = own ? sig * R - Qs : 0.0;
         const double pn = pm + kick * g;
         const double sn = sm + eps * v * pn;
@@ -1367,7 +1423,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             if (ci == 0) kin += (0.5 * v0 * p0n * p0n + 0.5 * v1 * p1n * p1n) + 0.5 * v2 * p2n * p2n;
             const double sqs = wave_sum(own ? sm * Qs : 0.0);
             if (lane == 0) {
-                double *fpw = ch.finpart + ((size_t)b * 32 + bx) * 4;
+                double *fpw = ch.finpart + ((size_t)b * ROLE_SLOTS + bx) * 4;
                 fpw[0] = kin; fpw[1] = 0.0; fpw[2] = sqs;
             }
             return;
@@ -1375,7 +1431,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         if (first) {
             double kin = wave_sum(own ? 0.5 * v * pm * pm : 0.0);
             if (ci == 0) kin += (0.5 * v0 * p0 * p0 + 0.5 * v1 * p1 * p1) + 0.5 * v2 * p2 * p2;
-            if (lane == 0) ch.k0part[(size_t)b * 32 + bx] = kin;
+            if (lane == 0) ch.k0part[(size_t)b * ROLE_SLOTS + bx] = kin;
         }
         // both softplus in one pass: lane 0 takes u0, the other lanes u1
         const double e0 = 2.220446049250313e-16;
@@ -1384,6 +1440,8 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const double sgx = cold_exp(ux - spx);             // sigmoid(u) = exp(u - softplus(u))
         const double psin = lane_value(spx, 0) + e0, sign = lane_value(spx, 1) + e0;
         const double s0n = lane_value(sgx, 0), s1n = lane_value(sgx, 1);
+        if (probe) { asm volatile("" :: "v"(psin), "v"(sign), "v"(s0n), "v"(s1n)); }
+        CPROBE(11);                                         // M-chunk: softplus and sigmoid of the new psi, sigma
         if (own) {
             q[oM + m] = sn; p[oM + m] = pn;
             spw[m] = sn;
@@ -1418,7 +1476,7 @@ __device__ __forceinline__ void hmc_final_apply(const Dims &d, const Consts &c, 
     double *q = ch.q + (size_t)b * d.Pp, *q0 = ch.q0 + (size_t)b * d.Pp, *var = ch.var + (size_t)b * d.Pp;
     double *hs = ch.hs + (size_t)b * NHS, *sc = w.scal + (size_t)b * NSCAL;
     const double *gr = w.gst + ((size_t)b * 2 + par) * GST_N;
-    const double *fp = ch.finpart + (size_t)b * 32 * 4;
+    const double *fp = ch.finpart + (size_t)b * ROLE_SLOTS * 4;
     const double e0 = 2.220446049250313e-16;
     // ---- the sums: the same in every role
     const bool isr = lane < nroles, ist = lane < ntc;
@@ -1586,7 +1644,7 @@ constexpr int TAIL_FLAG_STRIDE = 528;
 #define TAIL_FLAG_AT(B_, b_) ((size_t)(B_) * TAIL_STRIDE + (size_t)(b_) * TAIL_FLAG_STRIDE)
 template <int TSM, int NTC>
 __global__ __launch_bounds__(256)
-void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsigned long long target) {
+void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsigned long long target, int traj) {
     const int ntile = d.ntc * d.nmt, n_tiles = ntile * d.aff_nb;
     if ((int)blockIdx.x < n_tiles) {
         int bz, tile;
@@ -1625,7 +1683,10 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
     unsigned long long *stp = ch.tail + (size_t)b * TAIL_STRIDE + 8;
     if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_min(stp + 5, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    hmc_chunk_role<NTC, true>(d, c, w, s, ch, par, role, b, [&] {
+    // traj (hmc_mode 6: the whole trajectory as L + 1 of these launches): 1 = the trajectory's first step (the momentum is
+    // drawn here, the start point read from Chains::q0: k_hmc_step<0>'s work in chunk form), 2 = the step after it, 3 = the last
+    // half kick (the accept test follows in k_hmc_final); 0 = an inner step, the only kind the other forms launch
+    hmc_chunk_role<NTC, true, false, true>(d, c, w, s, ch, par, role, b, [&] {
         int spins = 0;
         // back off before the first look: since the roles fit beside all the tiles (96 VGPRs, five waves per SIMD) they
         // are resident from the start of the launch, and no tile phase of this size is shorter than the ~0.9 us slept
@@ -1649,7 +1710,7 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
             __hip_atomic_fetch_max(stp + 3, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #endif
-    });
+    }, -1, nullptr, nullptr, traj);
 #ifdef TAIL_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && par == 1) __hip_atomic_fetch_max(stp + 4, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2068,6 +2129,7 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
     // (hmc_chunk_role's traj 3, hmc_final_apply); without it k_hmc_step<2> does that as a launch of its own
     const bool fin_in = (fold & 4) != 0;
     const int nrole_steps = nsteps - (((fold & 2) && !fin_in) ? 1 : 0);
+    const double eps_l = ch.hs[(size_t)b_in * NHS + HS_EPS];   // the trajectory's step size (written again only at its end)
     for (int it = 0; it < nrole_steps; ++it) {
         // nothing of a role lives across the steps: without this the compiler hoists the step-invariant loads of the role
         // (variances, V(t), the I->R statistics, CAR rows ...) out of the loop and spills 500+ bytes per lane to hold them
@@ -2082,10 +2144,11 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         int lane_op = lane_w;
         asm volatile("" : "+v"(lane_op));
         auto wait_tiles = [&] {
-            if (nwg >= 32) __builtin_amdgcn_s_sleep(LEAP_BACKOFF);
             int spins = 0;                                       // every shard's tiles are in: all of (up to) eight flags show the step
+            // (the first look at once: a role that reaches its wait after the tiles -- most do, their waves get few issue slots
+            // while the tile waves of their SIMDs are at their cells -- must not sleep first; then the back-off, once)
             while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(flag1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stepno) != 0ull) {
-                __builtin_amdgcn_s_sleep(1);
+                if (spins == 0 && nwg >= 32) __builtin_amdgcn_s_sleep(LEAP_BACKOFF); else __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 if ((spins & 255) == 0 && __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // see leap_wait
                 if (spins > (1 << 21)) { if (lane_w == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -2098,7 +2161,7 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
             {
                 const bool first_ = (fold & 1) && it == 0;
                 const double *spr_ = first_ ? ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1 : w.sp + ((size_t)b * 2 + par) * d.Mp;
-                role_pregather<NTC>(d, spr_, role, wv, lane_op, gbuf);
+                role_pregather<NTC>(d, c, spr_, role, wv, lane_op, gbuf);
             }
             wait_tiles();
             role_gather<NTC>(d, w, b, role, wv, lane_op, gbuf);
@@ -2113,12 +2176,13 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
             if (threadIdx.x == 0) { LSTAMP_MIN(4); LSTAMP_MAX(5); }
             RPROBE(1);                                           // the step's tiles are in
         }, lane_op,
-#ifdef LEAP_STAMPS
-        (b == 0 && role == 0) ? ch.leap_st + ((size_t)1 * 16 + (it & 15)) * 8 : nullptr,
+#if defined(LEAP_STAMPS) && defined(LEAP_CPROBE)      // (the stamps INSIDE a role force its loads back early: they show the order of things, not the role's duration)
+        (b == 0 && role == 0) ? ch.leap_st + ((size_t)1 * 16 + (it & 15)) * 8 :
+        (b == 0 && role == d.ntc) ? ch.leap_st + ((size_t)2 * 16 + (it & 15)) * 8 : nullptr,
 #else
         nullptr,
 #endif
-        gbuf, (fin_in && it == nsteps - 1) ? 3 : (fold & 1) ? (it == 0 ? 1 : it == 1 ? 2 : 0) : 0);
+        gbuf, (fin_in && it == nsteps - 1) ? 3 : (fold & 1) ? (it == 0 ? 1 : it == 1 ? 2 : 0) : 0, eps_l, it > 0);
         RPROBE(2);                                               // stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this role's stores are in the XCD's L2
         RPROBE(3);
@@ -2166,6 +2230,26 @@ __global__ __launch_bounds__(WAVE) void k_vt(Dims d, Work w, Chains ch) {
 
 // XCC_ID of every workgroup of a grid laid out like the XCD-affine grids: the host checks that blocks with the same
 // id mod 8 share an XCD before it uses k_se_chunk.
+// The trajectory's end as a launch of its own for the per-step form (hmc_mode 6): every chunk role -- one wave -- makes the
+// accept test from the parts the last k_se_chunk launch's roles left and applies it to its entries (hmc_final_apply: what
+// k_leap's roles do behind their last hand-off, what k_hmc_step<2> does with one workgroup per chain in the stage forms).
+// Grid: (ntc + Mp / 64) x nb single-wave workgroups.
+template <int NTC>
+__global__ __launch_bounds__(WAVE) void k_hmc_final(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par) {
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (d.aff_nb > 0) xcd_affine(blockIdx.x, (NTC > 0 ? NTC : d.ntc) + d.Mp / WAVE, d.aff_nb, by, bx);
+    hmc_final_apply<NTC>(d, c, w, s, ch, par, bx, d.b0 + by, (int)threadIdx.x);
+}
+
+// The spatial effects of a trajectory's start point into the buffer the first gradient launch's tiles read them from
+// (Work::sp[par], M > 512 only: there the tiles form the row scalars) -- k_hmc_step<0> leaves them there in the stage forms.
+__global__ __launch_bounds__(256) void k_sp_prep(Dims d, Work w, Chains ch, int par) {
+    const int b = d.b0 + blockIdx.x;
+    const double *q0 = ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1;
+    double *sp = w.sp + ((size_t)b * 2 + par) * d.Mp;
+    for (int m = threadIdx.x; m < d.Mp; m += 256) sp[m] = m < d.M ? q0[m] : 0.0;
+}
+
 __global__ void k_xcc_probe(unsigned *out) {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));

@@ -1003,6 +1003,9 @@ struct seir_sampler {
     int prof_i = -1, prof_launches = 0, prof_evals = 0;  // next pair to record (-1: off); launches / gradient evaluations of the section in the last sweep
     bool hmc_fold = true;         // hmc_mode 0 / 5: the trajectory's first step and both end-point gradients inside k_leap as well
     bool hmc_end = true;          // hmc_mode 0: ... and its last half kick, accept test, adaptation and trace (5: k_hmc_step<2> does those)
+    bool hmc_tailfold = true;     // hmc_mode 0 (where k_leap does not fit) / 6: the trajectory's first and last step by the chunk roles of
+                                  // the per-step launches as well (L + 1 k_se_chunk launches and k_hmc_final instead of k_se, k_hmc_step<0>,
+                                  // L - 1 k_se_chunk, k_se, k_hmc_step<2>)
     bool vt_dirty = true;         // Work::Vt does not match Chains::var (set_kernel / set_adaptation / creation)
     unsigned long long leap_rsteps = 0;  // steps the ROLES of k_leap have done over all launches (the tiles do one more per folded launch)
     unsigned long long leap_steps = 0;   // leapfrog steps done by all k_leap launches so far (what Chains::leap's flags show)
@@ -1080,6 +1083,8 @@ static void apply_launch_form(seir_sampler *s, int hmc_mode, int moves_mode) {
     s->hmc_leap = hmc_mode == 0 || hmc_mode == 4 || hmc_mode == 5;
     s->hmc_fold = hmc_mode == 0 || hmc_mode == 5;
     s->hmc_end = hmc_mode == 0;
+    s->hmc_tailfold = hmc_mode == 0 || hmc_mode == 6;
+    if (hmc_mode == 6) s->hmc_tail = true;
     s->moves_mode = moves_mode;
 }
 
@@ -1100,8 +1105,8 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     if (ds->num_leapfrog_steps < 1) return fail(SEIR_ERR_INVALID, "num_leapfrog_steps must be >= 1");
     if (ds->trace_capacity < 1) return fail(SEIR_ERR_INVALID, "trace_capacity must be >= 1");
     if (ds->record_events < 0 || ds->record_events > 2) return fail(SEIR_ERR_INVALID, "record_events is 0, 1 or 2");
-    if (ds->moves_mode < 0 || ds->moves_mode > 4 || ds->hmc_mode < 0 || ds->hmc_mode > 5)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..5");
+    if (ds->moves_mode < 0 || ds->moves_mode > 4 || ds->hmc_mode < 0 || ds->hmc_mode > 6)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..6");
     if (ds->disable_mask < 0 || ds->disable_mask > 31) return fail(SEIR_ERR_INVALID, "disable_mask is a 5-bit mask");
     if (ds->leap_rows != 0 && ds->leap_rows != 24 && ds->leap_rows != 32) return fail(SEIR_ERR_INVALID, "leap_rows is 0 (auto), 24 or 32");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1170,12 +1175,12 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     ch.late_fatal = B;
     S_HAND(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
     S_HAND(ch.leap, (size_t)B * LEAP_CH);
-    S_HAND(ch.k0part, (size_t)B * 32);
+    S_HAND(ch.k0part, (size_t)B * ROLE_SLOTS);
     S_HAND(ch.irl0, (size_t)B);
     S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
     S_HAND(ch.done, (size_t)B * 2 * TAIL_STRIDE);
     S_HAND(ch.pbar, (size_t)B * PBAR_STRIDE);
-    S_HAND(ch.finpart, (size_t)B * 32 * 4);
+    S_HAND(ch.finpart, (size_t)B * ROLE_SLOTS * 4);
     S_HAND(ch.hand2, (size_t)B);
     S_HAND(ch.mvs, (size_t)2 * B);
     S_HAND(ch.DownS, (size_t)2 * B * 2);
@@ -1262,8 +1267,8 @@ static int reset_handoffs(seir_sampler *s) {
 extern "C" int seir_sampler_set_launch_form(seir_sampler *s, int32_t hmc_mode, int32_t moves_mode) {
     int rc = sampler_check(s);
     if (rc) return rc;
-    if (moves_mode < 0 || moves_mode > 4 || hmc_mode < 0 || hmc_mode > 5)
-        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..5");
+    if (moves_mode < 0 || moves_mode > 4 || hmc_mode < 0 || hmc_mode > 6)
+        return fail(SEIR_ERR_INVALID, "moves_mode is 0..4, hmc_mode 0..6");
     if (hmc_mode != s->hmc_mode || moves_mode != s->moves_mode) {
         HIP_TRY(hipStreamSynchronize(s->ctx->stream));
         drop_graph(s);                               // the captured sweep is one form's launches
@@ -1654,6 +1659,59 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             launch_hmc(ctx, l, c, s->ch, 2, /*gather_qs=*/3);
             l.d.nmt = d0.nmt;
         }
+    } else if (chunked && s->hmc_tailfold && s->hmc_tail && s->xcd_local && nbv_all > 0 && s->ngroups == 1 && (l.affinity & 1) &&
+               xcd_affinity_applies(ntile_all, nbv_all) && !s->use_graph && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && c.L >= 3 && per_roles <= ROLE_SLOTS) {
+        // The whole trajectory as L + 1 launches of k_se_chunk -- where the persistent launch does not fit the chip (16+ chains
+        // at UK-380, SYN-2048) -- with the trajectory's first step (momentum draw, half kick: traj 1), the step after it (2) and
+        // the last half kick (3) by the chunk roles of those launches, and the accept test, adaptation and trace by the roles'
+        // own launch (k_hmc_final): what k_se, k_hmc_step<0>, ..., k_se, k_hmc_step<2> do in the stage form (hmc_mode 3), and
+        // what k_leap's roles do inside the persistent launch.  Buffers alternate from 1, as there.
+        if (s->vt_dirty || c.adapt_mass) {
+            hipLaunchKernelGGL(k_vt, dim3(nb), dim3(WAVE), 0, st, l.d, ctx->w, s->ch);
+            s->vt_dirty = false;
+        }
+        int par = 1;
+        if (ts_mode == 2) hipLaunchKernelGGL(k_sp_prep, dim3(nb), dim3(256), 0, st, l.d, ctx->w, s->ch, par);
+        if (prof0) (void)hipEventRecord(s->prof_ev[2 * s->prof_i], st);
+        const int per = d0.ntc + d0.Mp / WAVE;
+        Dims df = l.d;
+        df.aff_nb = nbv_all;
+        df.nlive = nbv_all != nb ? nb : 0;
+        df.chunked = ts_mode;
+        const dim3 gf((unsigned)((ntile_all + per) * nbv_all));      // tiles, then the chunk roles
+        for (int it = 0; it <= c.L; ++it) {
+            const int traj = it == 0 ? 1 : it == 1 ? 2 : it == c.L ? 3 : 0;
+            df.sp_par = par;
+            Work wf = ctx->w;
+            if (it == 0) wf.Lpart = wf.Lpart0;                    // the start point's value of the S->E term: kept for the accept test
+            s->tail_count += (unsigned long long)ntile_all;
+            const unsigned long long target = s->tail_count;
+#define LAUNCH_TAILF(TSM_, NTC_) hipLaunchKernelGGL((k_se_chunk<TSM_, NTC_>), gf, dim3(256), 0, st, df, ctx->c, wf, c, s->ch, par, target, traj)
+            if (ts_mode == 1) {
+                if (d0.ntc == 1) LAUNCH_TAILF(1, 1); else if (d0.ntc == 6) LAUNCH_TAILF(1, 6); else LAUNCH_TAILF(1, 12);
+            } else {
+                if (d0.ntc == 1) LAUNCH_TAILF(2, 1); else if (d0.ntc == 6) LAUNCH_TAILF(2, 6); else LAUNCH_TAILF(2, 12);
+            }
+#undef LAUNCH_TAILF
+            if (it < c.L) par ^= 1;
+        }
+        {
+            Dims dz = l.d;
+            const bool aff = xcd_affinity_applies(per, nb);
+            dz.aff_nb = aff ? nb : 0;
+            const dim3 gz = aff ? dim3(per * nb) : dim3(per, nb);
+            switch (d0.ntc) {
+                case 1: hipLaunchKernelGGL(k_hmc_final<1>, gz, dim3(WAVE), 0, st, dz, ctx->c, ctx->w, c, s->ch, par); break;
+                case 6: hipLaunchKernelGGL(k_hmc_final<6>, gz, dim3(WAVE), 0, st, dz, ctx->c, ctx->w, c, s->ch, par); break;
+                default: hipLaunchKernelGGL(k_hmc_final<12>, gz, dim3(WAVE), 0, st, dz, ctx->c, ctx->w, c, s->ch, par); break;
+            }
+        }
+        if (prof0) {
+            (void)hipEventRecord(s->prof_ev[2 * s->prof_i + 1], st);
+            s->prof_i += 1;
+            s->prof_launches = c.L + 2;
+            s->prof_evals = c.L + 1;
+        }
     } else {
     l.d.chunked = 0;                       // k_se writes tile scalars only ahead of a chunked step
     launch_se<1>(ctx, l, true);
@@ -1698,7 +1756,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
                 const dim3 gf((unsigned)((ntile_se + per) * nbv));     // tiles, then the chunk roles
                 s->tail_count += (unsigned long long)ntile_se;         // what a chain's counter shows once this launch's tiles are in
                 const unsigned long long target = s->tail_count;
-#define LAUNCH_TAIL(TSM_, NTC_) hipLaunchKernelGGL((k_se_chunk<TSM_, NTC_>), gf, dim3(256), 0, st, df, ctx->c, ctx->w, c, s->ch, par, target)
+#define LAUNCH_TAIL(TSM_, NTC_) hipLaunchKernelGGL((k_se_chunk<TSM_, NTC_>), gf, dim3(256), 0, st, df, ctx->c, ctx->w, c, s->ch, par, target, 0)
                 if (ts_mode == 1) {
                     if (d0.ntc == 1) LAUNCH_TAIL(1, 1); else if (d0.ntc == 6) LAUNCH_TAIL(1, 6); else LAUNCH_TAIL(1, 12);
                 } else {

@@ -21,7 +21,8 @@ from .seir import SeirModel, _dptr
 
 MOVE_KEYS = ("move/S->E", "move/E->I", "occult/S->E", "occult/E->I")   # inference.py:277-280
 MOVES_MODES = {"paired": 0, "split": 1, "paired-nopre": 2, "paired-delta": 3, "paired-launch": 4}
-HMC_MODES = {"chunk": 0, "single": 1, "chunk-split": 2, "chunk-launch": 3, "chunk-leap": 4, "chunk-stage": 5}
+HMC_MODES = {"chunk": 0, "single": 1, "chunk-split": 2, "chunk-launch": 3, "chunk-leap": 4, "chunk-stage": 5,
+             "chunk-launch-fold": 6}
 # Launch forms to fall back on when a hand-off inside a persistent launch times out (the GPU is shared with something):
 # first the per-step forms, whose waiting workgroups are always placed behind the ones they wait for, then the forms
 # without any hand-off inside a launch.  What is sampled is the same in all of them.

@@ -217,6 +217,10 @@ typedef struct {
                                        once; else one launch per step with the chunk roles inside the gradient launch
                                        (k_se_chunk; needs the XCD placement only) between the stage kernels
                                        (k_hmc_step<0>, <2>); else the chunks as their own launch (k_hmc_chunk).
+                                       Where the persistent launch does not fit (16+ chains at UK-380, SYN-2048) mode 0 runs
+                                       as 6: the whole trajectory as L + 1 per-step launches (k_se_chunk) whose chunk roles also
+                                       do the trajectory's first step and last half kick, and k_hmc_final (the accept test,
+                                       adaptation and trace by the roles) -- no single-workgroup stage kernel.
                                        5: as 0 with the last half kick, accept test, adaptation and trace by
                                        k_hmc_step<2> as a launch of its own; 4: the persistent launch for the inner steps
                                        only; 3: one launch per step (k_se_chunk), never the persistent one; 2: chunks always
@@ -326,6 +330,8 @@ int seir_sampler_pair_timeouts(seir_sampler *s, uint32_t *out);
  *                                        launches = 1, evals = L+1;
  *   hmc_mode 5                           the same launch without the trajectory's end: launches = 1, evals = L+1;
  *   hmc_mode 4                           k_leap for the inner steps 1..L-1 only: launches = 1, evals = L-1;
+ *   hmc_mode 6 (and 0 where k_leap       the whole trajectory as L+1 k_se_chunk launches and k_hmc_final:
+ *     does not fit)                      launches = L+2, evals = L+1;
  *   hmc_mode 3 / 2                       the inner steps 1..L-1 as one k_se_chunk launch each (launches = L-1) or as
  *                                        k_se + k_hmc_chunk (launches = 2(L-1)): evals = L-1.
  * mean_ms = mean duration of that section.  The chains advance as in seir_sampler_run. */

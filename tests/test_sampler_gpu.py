@@ -685,7 +685,7 @@ def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
     out = {}
     rows_of = {}
     for mode, skew in (("chunk-split", 0), ("chunk-launch", 0), ("chunk-leap", 0), ("chunk-stage", 0), ("chunk", 0), ("chunk", 3),
-                       ("chunk/32", 0), ("chunk-stage/32", 0)):
+                       ("chunk/32", 0), ("chunk-stage/32", 0), ("chunk-launch-fold", 0), ("chunk-launch-fold", 2)):
         # "/32": the 32-row tile shape of the persistent launch where the default is the 24-row one (UK-380)
         mode, _, rows_ = mode.partition("/")
         rows_of[(mode, skew)] = rows_
@@ -713,6 +713,15 @@ def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
         got, got_state = out[(mode, 0)]
         _same_chain_up_to_rounding(ref, got)
         np.testing.assert_allclose(got_state[2], ref_state[2], rtol=1e-11, atol=0.0)
+    # the per-step form that carries the trajectory's ends itself (what 16+ chains and SYN-2048 run by default): against the
+    # stage form up to rounding, against itself under workgroup skew to the bit
+    got, got_state = out[("chunk-launch-fold", 0)]
+    _same_chain_up_to_rounding(ref, got)
+    np.testing.assert_allclose(got_state[2], ref_state[2], rtol=1e-11, atol=0.0)
+    sk, sk_state = out[("chunk-launch-fold", 2)]
+    assert np.array_equal(sk.theta, got.theta) and np.array_equal(sk.events, got.events) and np.array_equal(sk_state[2], got_state[2])
+    for k in got.hmc:
+        assert np.array_equal(sk.hmc[k], got.hmc[k]), k
     for key in (("chunk", 32), ("chunk-stage", 32)):             # ... in the other tile shape too
         if key in out:
             got, got_state = out[key]
@@ -745,7 +754,7 @@ def test_trajectory_end_inside_the_launch_accepts_rejects_and_adapts_like_the_st
     seen = []
     for scale in (1.0, 2.5):
         out = {}
-        for mode in ("chunk-stage", "chunk"):
+        for mode in ("chunk-stage", "chunk", "chunk-launch-fold"):
             with api[0](case["cov"], case["init"], max_chains=B) as model:
                 with api[1](model, cfg, B, seed=29, trace_capacity=n, hmc=mode) as s:
                     if not s.xcd_local():
@@ -758,18 +767,19 @@ def test_trajectory_end_inside_the_launch_accepts_rejects_and_adapts_like_the_st
                     out[mode] = (s.sample(n), s.get_state(), s.get_kernel())
                     assert not s.pair_timeouts().any()
         ref, ref_state, ref_k = out["chunk-stage"]
-        got, got_state, got_k = out["chunk"]
         acc = ref.hmc["is_accepted"].astype(bool)
-        assert np.array_equal(acc, got.hmc["is_accepted"].astype(bool))
         seen.append(acc)
-        _same_chain_up_to_rounding(_head(ref, 5), _head(got, 5), rtol=1e-7)
-        # a rejected HMC update leaves the parameters of the previous draw (the event updates do not touch them)
-        for t in range(1, n):
-            for b in range(B):
-                if not got.hmc["is_accepted"][t, b]:
-                    assert np.array_equal(got.theta[t, b], got.theta[t - 1, b]), (t, b)
-        np.testing.assert_allclose(got_k[0], ref_k[0], rtol=1e-5)
-        np.testing.assert_allclose(got_k[1], ref_k[1], rtol=1e-5)
+        for form in ("chunk", "chunk-launch-fold"):          # the end inside the persistent launch / by k_hmc_final after the per-step launches
+            got, got_state, got_k = out[form]
+            assert np.array_equal(acc, got.hmc["is_accepted"].astype(bool)), form
+            _same_chain_up_to_rounding(_head(ref, 5), _head(got, 5), rtol=1e-7)
+            # a rejected HMC update leaves the parameters of the previous draw (the event updates do not touch them)
+            for t in range(1, n):
+                for b in range(B):
+                    if not got.hmc["is_accepted"][t, b]:
+                        assert np.array_equal(got.theta[t, b], got.theta[t - 1, b]), (form, t, b)
+            np.testing.assert_allclose(got_k[0], ref_k[0], rtol=1e-5)
+            np.testing.assert_allclose(got_k[1], ref_k[1], rtol=1e-5)
     allacc = np.concatenate([a.ravel() for a in seen])
     assert allacc.any() and not allacc.all(), allacc.mean()     # both branches were taken
 

@@ -40,6 +40,10 @@ with SeirModel(cov, init, max_chains=B) as model:
         more = st[:, 3, 1:14, :5] - st[:, B, 1:14, :1]
         print("T-chunk 0 inside: column sums in %.0f; before the wait: entry loads issued %.0f, back + two wave sums %.0f, I->R part done %.0f" % (
             np.median(more[..., 0]), np.median(more[..., 2]), np.median(more[..., 3]), np.median(more[..., 4])))                            # [rep, T-chunk 0 / M-chunk 0, step, stamp]
+        mi = st[:, 2, 1:14, 5:8] - st[:, B, 1:14, :1]           # M-chunk 0: entry loads issued, (Q s) formed, at the wait
+        mm = st[:, 4, 1:14, :4] - st[:, B, 1:14, :1]            # ... partial sums in, -, three wave sums, softplus done
+        print("M-chunk 0 inside: entry loads issued %.0f, (Q s) formed %.0f, at the wait %.0f | partial sums in %.0f, wave sums %.0f, softplus %.0f" % (
+            np.median(mi[..., 0]), np.median(mi[..., 1]), np.median(mi[..., 2]), np.median(mm[..., 0]), np.median(mm[..., 2]), np.median(mm[..., 3])))
         period = np.median(tiles[:, 0, 2:15, 0] - tiles[:, 0, 1:14, 0])
         print(f"step period (tile 0 past its wait, step to step): median {period:.0f} ns; whole launch ~{period * 15 / 1e3:.1f} us")
         first = np.median(tiles[:, 0, 1, 0] - tiles[:, 0, 0, 0])
