@@ -110,6 +110,13 @@ struct Chains {
                                                          //         the start point's kinetic energy
     double *irl0;                                        // [B] ... and the I->R term of its log-probability
     unsigned long long *leap_st;                         // [B][16][8] developer timeline of k_leap (LEAP_STAMPS builds only)
+    // k_leap's hand-offs as self-validating words (below: "Hand-off words"): what a tile leaves for the roles, per step parity
+    uint4 *llK;                                          // [B][2][Mp/16][Tp]   column sums (Work::Kpart)
+    uint4 *llR;                                          // [B][2][ntc][Mp]     row sums (Work::Rpart)
+    uint4 *llP;                                          // [B][2][ntc Mp/16]   psi parts (Work::Ppart)
+    uint4 *llTS;                                         // [B][2][ntc Mp/16][4] tile scalars (Work::TS)
+    uint4 *llT;                                          // [B][Tp + 2 Mp + 8]  ... and what the roles leave for the tiles: exp(a_t) | exp(b_m)/N_m |
+                                                         //     spatial effects | psi (Work::ea, eb, sp, scal[SC_PSI])
     unsigned *hand2;                                     // [B] the same token for role 2 (pre-drawn S->E-type proposal)
     Move *mvs;                                           // [2][B] S->E-type proposal pre-drawn for the next launch (k_move_pair, role 2)
     double *DownS;                                       // [2][B][2] its own-rows log-ratio {theta, const}
@@ -127,6 +134,78 @@ struct Chains {
     double *tr_hmc;                                      // [cap][B][3]  is_accepted, target_log_prob, step_size
     double *tr_mv;                                       // [cap][B][4][NMVTR]
 };
+
+// ---------------------------------------------------------------------------------------------
+// Hand-off words (k_leap).  A value handed from one workgroup of a launch to another through the XCD's L2 used to cost the
+// producer its stores, the wait for their acknowledgement (s_waitcnt vmcnt(0), ~0.3 us), a returning atomic on the chain's
+// counter (~0.4 us) and -- for the last one in -- a flag store; the consumer a poll of the flag (a round trip, ~0.5 us) and only
+// then the loads of the values (another).  Here every value carries its own flag: a double travels as 16 bytes
+// {low word, seq, high word, seq} -- two aligned 8-byte halves, each written whole by the memory system, each with the step
+// number -- so the producer only issues its stores and the consumer's first look at the DATA is also its wait: it loads past
+// the L1 and looks again until both halves of everything it asked for show the step.  seq = the step's number over all
+// launches of the sampler with the top bit set: never the zero of a reset buffer, never the number of the step before.
+// No release / acquire anywhere: all of a chain's workgroups share one L2 (checked at creation, as for every hand-off here).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned ll_seq(unsigned long long step) { return (unsigned)step | 0x80000000u; }
+__device__ __forceinline__ void ll_store(uint4 *p, double v, unsigned seq) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    uint4 x;
+    x.x = (unsigned)u; x.y = seq; x.z = (unsigned)(u >> 32); x.w = seq;
+    *p = x;                                                 // one global_store_dwordx4
+}
+__device__ __forceinline__ bool ll_ok(const u32x4 &x, unsigned seq) { return x.y == seq && x.w == seq; }
+__device__ __forceinline__ double ll_value(const u32x4 &x) {
+    return __longlong_as_double((long long)(((unsigned long long)x.z << 32) | (unsigned long long)x.x));
+}
+// N 16-byte loads past the L1 and the wait for them, as ONE asm block: the compiler does not count these loads, so nothing
+// may touch the destination registers between the issue and the wait
+template <int N> __device__ __forceinline__ void ll_load(const uint4 *const (&p)[N], u32x4 (&x)[N]) {
+    static_assert(N >= 1 && N <= 6, "groups of up to six");
+    if constexpr (N == 1)
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x[0]) : "v"(p[0]) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]) : "v"(p[0]), "v"(p[1]) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)" : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]) : "v"(p[0]), "v"(p[1]), "v"(p[2]) : "memory");
+    else if constexpr (N == 4)
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+    else if constexpr (N == 5)
+        asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                     "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]) : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %7, off sc1\n\tglobal_load_dwordx4 %2, %8, off sc1\n\t"
+                     "global_load_dwordx4 %3, %9, off sc1\n\tglobal_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %11, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]) : "memory");
+}
+// The consumer's wait: load, look, again -- until every lane of the wave has the step's words in all N places.  Bounded like
+// every wait of k_leap (leap_wait): a time-out is counted in the chain's fatal counter, and once that is non-zero every wait
+// of the chain gives up at its next look at it; the values are then whatever was there -- the host discards the burst.
+template <int N> __device__ __forceinline__ void ll_poll(const uint4 *const (&p)[N], unsigned seq, unsigned *late, double (&v)[N]) {
+    u32x4 x[N];
+    int spins = 0;
+    for (;;) {
+        ll_load<N>(p, x);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) ok = ok && ll_ok(x[j], seq);
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+        if ((spins & 63) == 0 && __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (spins > (1 << 19)) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = ll_value(x[j]);
+}
 
 __device__ inline RngKey rng_key(const SamplerCfg &s, const Chains &ch, int b) {
     return RngKey{s.k0, s.k1, (uint32_t)(s.chain0 + b), ch.sweep[b]};
@@ -865,70 +944,118 @@ __device__ __forceinline__ void role_pregather(const Dims &d, const Consts &c, c
         g[G::SX + kk * WAVE + lane] = on ? sv_ : 0.0;
     }
 }
+// What a role needs to know about the step's hand-off words: the number the tiles' words of THIS step carry and their buffer
+// (steps alternate), the number the role's own tables for the NEXT step must carry, the chain's time-out counter
+struct LeapLL {
+    unsigned seq_in = 0, seq_out = 0;
+    int pb = 0;
+    unsigned *late = nullptr;
+};
+__device__ __forceinline__ size_t ll_tab_len(const Dims &d) { return (size_t)d.Tp + 2 * (size_t)d.Mp + 8; }
+// N places in groups of up to six loads
+template <int N> __device__ __forceinline__ void ll_poll_many(const uint4 *const (&p)[N], unsigned seq, unsigned *late, double (&v)[N]) {
+    if constexpr (N <= 6) {
+        ll_poll<N>(p, seq, late, v);
+    } else {
+        constexpr int H = N / 2;
+        const uint4 *pa[H], *pb_[N - H];
+        double va[H], vb[N - H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) pa[j] = p[j];
+#pragma unroll
+        for (int j = 0; j < N - H; ++j) pb_[j] = p[H + j];
+        ll_poll_many<H>(pa, seq, late, va);
+        ll_poll_many<N - H>(pb_, seq, late, vb);
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = va[j];
+#pragma unroll
+        for (int j = 0; j < N - H; ++j) v[H + j] = vb[j];
+    }
+}
 template <int NTC>
-__device__ __forceinline__ void role_gather(const Dims &d, const Work &w, int b, int bx, int wv, int lane, double *g) {
-    auto LDP = [](const double *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+__device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, const LeapLL &ll, int b, int bx, int wv, int lane, double *g) {
     constexpr int NC = NTC > 0 ? NTC : CT_MAXC;
     using G = RoleGather<NC>;
     const int nmt = d.nmt, ntc = NTC > 0 ? NTC : d.ntc, ntile = nmt * ntc, M = d.M;
-    const double *TS = w.TS + (size_t)b * ntile * 4;
+    const int nmt16 = d.Mp / 16;                                 // row tiles the arrays are laid out for
+    const size_t cb = (size_t)b * 2 + ll.pb;                     // (chain, parity)
+    const uint4 *TS = ch.llTS + cb * ((size_t)ntc * nmt16) * 4;
     if (bx < ntc) {
         const int t = bx * WAVE + lane;
-        const double *kp = w.Kpart + (size_t)b * nmt * d.Tp + t;
+        const uint4 *kp = ch.llK + cb * nmt16 * d.Tp + t;
         double cw = 0.0;
-        for (int j0 = 0; j0 < nmt; j0 += 24) {
-            double x[6];
+        if (nmt <= 16) {                                         // (uniform) four row tiles per wave
+            const uint4 *pp[4];
+            double x[4];
 #pragma unroll
-            for (int jj = 0; jj < 6; ++jj) {
-                const int j = j0 + wv + 4 * jj;
-                const double v_ = LDP(kp + (size_t)min(j, nmt - 1) * d.Tp);
-                x[jj] = j < nmt ? v_ : 0.0;
+            for (int jj = 0; jj < 4; ++jj) pp[jj] = kp + (size_t)min(wv + 4 * jj, nmt - 1) * d.Tp;
+            ll_poll<4>(pp, ll.seq_in, ll.late, x);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) cw += wv + 4 * jj < nmt ? x[jj] : 0.0;
+        } else {
+            for (int j0 = 0; j0 < nmt; j0 += 24) {
+                const uint4 *pp[6];
+                double x[6];
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) pp[jj] = kp + (size_t)min(j0 + wv + 4 * jj, nmt - 1) * d.Tp;
+                ll_poll<6>(pp, ll.seq_in, ll.late, x);
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) cw += j0 + wv + 4 * jj < nmt ? x[jj] : 0.0;
             }
-#pragma unroll
-            for (int jj = 0; jj < 6; ++jj) cw += x[jj];
         }
-        double b_[(NC + 3) / 4], a_[(NC + 3) / 4];
+        constexpr int NI = (NC + 3) / 4;
+        const uint4 *tp[2 * NI];
+        double ba[2 * NI];
 #pragma unroll
-        for (int i = 0; i < (NC + 3) / 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int cc = wv + 4 * i;
-            const double *tp_ = TS + ((size_t)min(lane, nmt - 1) * ntc + min(cc, ntc - 1)) * 4;
-            b_[i] = LDP(tp_); a_[i] = LDP(tp_ + 1);
+            const uint4 *tp_ = TS + ((size_t)min(lane, nmt - 1) * ntc + min(cc, ntc - 1)) * 4;
+            tp[2 * i] = tp_; tp[2 * i + 1] = tp_ + 1;
         }
+        ll_poll_many<2 * NI>(tp, ll.seq_in, ll.late, ba);
         g[G::C + wv * WAVE + lane] = cw;
 #pragma unroll
-        for (int i = 0; i < (NC + 3) / 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int cc = wv + 4 * i;
             const bool on = cc < ntc && lane < nmt;
-            if (cc < NC) { g[G::BS + cc * WAVE + lane] = on ? b_[i] : 0.0; g[G::AS + cc * WAVE + lane] = on ? a_[i] : 0.0; }
+            if (cc < NC) { g[G::BS + cc * WAVE + lane] = on ? ba[2 * i] : 0.0; g[G::AS + cc * WAVE + lane] = on ? ba[2 * i + 1] : 0.0; }
         }
     } else {
         const int ci = bx - ntc, m = ci * WAVE + lane;
         const bool own = m < M;
         const bool rows_here = d.chunked == 1;
+        const uint4 *R = ch.llR + cb * ntc * d.Mp;
         if (wv == 1) {
-            const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (own ? m : 0);
+            const uint4 *rp[NC];
             double x[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) { const double v_ = LDP(rp + (size_t)min(j, ntc - 1) * d.Mp); x[j] = (own && j < ntc) ? v_ : 0.0; }
+            for (int j = 0; j < NC; ++j) rp[j] = R + (size_t)min(j, ntc - 1) * d.Mp + (own ? m : 0);
+            ll_poll_many<NC>(rp, ll.seq_in, ll.late, x);
 #pragma unroll
-            for (int j = 0; j < NC; ++j) g[G::X + j * WAVE + lane] = x[j];
+            for (int j = 0; j < NC; ++j) g[G::X + j * WAVE + lane] = (own && j < ntc) ? x[j] : 0.0;
         }
         if (wv == 2) {
+            const uint4 *P = ch.llP + cb * ((size_t)ntc * nmt16);
             double ps = 0.0, rl = 0.0, rs = 0.0;
             for (int i0 = lane; i0 < ntile; i0 += 4 * WAVE) {
+                const uint4 *pp[4];
                 double x[4], y[4], z[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = i0 + j * WAVE;
-                    const bool on = i < ntile;
-                    const int ic = on ? i : 0;
-                    const double xv = LDP(w.Ppart + (size_t)b * ntile + ic);
-                    x[j] = on ? xv : 0.0;
-                    y[j] = 0.0; z[j] = 0.0;
-                    if (!rows_here) {                            // uniform
-                        const double yv = LDP(TS + (size_t)ic * 4 + 2), zv = LDP(TS + (size_t)ic * 4 + 3);
-                        y[j] = on ? yv : 0.0; z[j] = on ? zv : 0.0;
+                for (int j = 0; j < 4; ++j) pp[j] = P + (i0 + j * WAVE < ntile ? i0 + j * WAVE : 0);
+                ll_poll<4>(pp, ll.seq_in, ll.late, x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { if (!(i0 + j * WAVE < ntile)) x[j] = 0.0; y[j] = 0.0; z[j] = 0.0; }
+                if (!rows_here) {                                // uniform
+                    const uint4 *yp[4], *zp[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ic = i0 + j * WAVE < ntile ? i0 + j * WAVE : 0;
+                        yp[j] = TS + (size_t)ic * 4 + 2; zp[j] = TS + (size_t)ic * 4 + 3;
                     }
+                    ll_poll<4>(yp, ll.seq_in, ll.late, y);
+                    ll_poll<4>(zp, ll.seq_in, ll.late, z);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (!(i0 + j * WAVE < ntile)) { y[j] = 0.0; z[j] = 0.0; }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ps += x[j]; rl += y[j]; rs += z[j]; }
@@ -942,13 +1069,14 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Work &w, int b,
                 if (role_gather_row_wave(kk) != wv || kk >= nrow) continue;
                 const int mm = lane + kk * WAVE;
                 const bool on = mm < M;
-                const double *rp = w.Rpart + (size_t)b * ntc * d.Mp + (on ? mm : 0);
+                const uint4 *rp[NC];
                 double x[NC];
 #pragma unroll
-                for (int j = 0; j < NC; ++j) { const double v_ = LDP(rp + (size_t)(j < ntc ? j : 0) * d.Mp); x[j] = (on && j < ntc) ? v_ : 0.0; }
+                for (int j = 0; j < NC; ++j) rp[j] = R + (size_t)(j < ntc ? j : 0) * d.Mp + (on ? mm : 0);
+                ll_poll_many<NC>(rp, ll.seq_in, ll.late, x);
                 double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) acc += x[j];
+                for (int j = 0; j < NC; ++j) acc += (on && j < ntc) ? x[j] : 0.0;
                 g[G::ACC + kk * WAVE + lane] = acc;
             }
         }
@@ -964,7 +1092,7 @@ template <int NTC, bool COH, bool PERS = false, bool TRAJ = PERS, typename Wait>
 __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
                                                const Chains &ch, int par, int bx, int b, Wait wait, int lane_in = -1,
                                                unsigned long long *probe = nullptr, double *gbuf = nullptr, int traj = 0,
-                                               double eps_in = 0.0, bool tab_ready = false) {
+                                               double eps_in = 0.0, bool tab_ready = false, const LeapLL &ll = LeapLL{}) {
 #ifdef LEAP_STAMPS
 #define CPROBE(k) do { asm volatile("s_nop 0" ::: "memory"); if (probe && threadIdx.x == 0) probe[(k) < 8 ? (k) : 2 * 128 + (k) - 8] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -1133,7 +1261,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         if (PERS) {
             // the four waves of the workgroup fetch a quarter each (role_gather); wave 0 is this one
             using G = RoleGather<NC>;
-            role_gather<NTC>(d, w, b, bx, 0, lane, gbuf);
+            role_gather<NTC>(d, ch, ll, b, bx, 0, lane, gbuf);
             lds_barrier();
             col = (gbuf[G::C + lane] + gbuf[G::C + WAVE + lane]) + (gbuf[G::C + 2 * WAVE + lane] + gbuf[G::C + 3 * WAVE + lane]);
 #pragma unroll
@@ -1235,8 +1363,10 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         const double ca = wave_sum(an), cvp = wave_sum(v * pn), cva = wave_sum(v * an);
         if (own) { q[oT + t] = an; p[oT + t] = pn; }
         if (t < T) {
+            const double ea_new = exp(a_new);
             w.acur[(size_t)b * d.Tp + t] = a_new;
-            w.ea[(size_t)b * d.Tp + t] = exp(a_new);
+            w.ea[(size_t)b * d.Tp + t] = ea_new;
+            if (PERS) ll_store(ch.llT + (size_t)b * ll_tab_len(d) + t, ea_new, ll.seq_out);   // what the tiles of the next step wait for
             w.rir[(size_t)b * d.Tp + t] = rnew;            // read by nobody in this launch
         }
         if (lane == 0) {
@@ -1335,7 +1465,7 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         double ps = 0.0, rl = 0.0, rs = 0.0;
         if (PERS) {
             using G = RoleGather<NC>;
-            role_gather<NTC>(d, w, b, bx, 0, lane, gbuf);
+            role_gather<NTC>(d, ch, ll, b, bx, 0, lane, gbuf);
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < NC; ++j) R += gbuf[G::X + j * WAVE + lane];
@@ -1443,10 +1573,17 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         if (probe) { asm volatile("" :: "v"(psin), "v"(sign), "v"(s0n), "v"(s1n)); }
         CPROBE(11);                                         // M-chunk: softplus and sigmoid of the new psi, sigma
         if (own) {
+            const double eb_new = exp(betan * lm + sign * sn) * inN;
             q[oM + m] = sn; p[oM + m] = pn;
             spw[m] = sn;
-            w.eb[(size_t)b * d.Mp + m] = exp(betan * lm + sign * sn) * inN;
+            w.eb[(size_t)b * d.Mp + m] = eb_new;
+            if (PERS) {                                     // the tiles of the next step wait for these
+                uint4 *lt = ch.llT + (size_t)b * ll_tab_len(d) + d.Tp;
+                ll_store(lt + m, eb_new, ll.seq_out);
+                ll_store(lt + d.Mp + m, sn, ll.seq_out);
+            }
         }
+        if (PERS && ci == 0 && lane == 0) ll_store(ch.llT + (size_t)b * ll_tab_len(d) + d.Tp + 2 * (size_t)d.Mp, psin, ll.seq_out);
         if (ci == 0 && lane == 0) {
             q[0] = u0n; q[1] = u1n; q[2] = betan; p[0] = p0n; p[1] = p1n; p[2] = p2n;
             gw[0] = u0n; gw[1] = u1n; gw[2] = betan; gw[6] = p0n; gw[7] = p1n; gw[8] = p2n;
@@ -1852,7 +1989,6 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
     // this workgroup's shard of the chain's counters: workgroups g, g + nsh, g + 2 nsh ... count in together
     const int tix = byg * d.ntc + bx, nsh = min(LEAP_NSH, nwg), shard = tix % nsh;
     const unsigned long long shard_size = (unsigned long long)((nwg - shard + nsh - 1) / nsh);
-    const unsigned long long *flag2 = LEAP_FLAG2(b, shard);
     unsigned long long *cnt1 = LEAP_CNT1(b, shard), *flag1 = LEAP_FLAG1(b, shard);
     __syncthreads();                                             // ltab
     // The S->E term's VALUE at the trajectory's two end points (fold bits 0 and 1), from the tables in `tabbuf`: NOT part of
@@ -1916,6 +2052,43 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             if (lane == 0) tabbuf[TB_PSI] = LDP(w.scal + (size_t)b * NSCAL + SC_PSI);
         }
     };
+    // ... from the second step on as hand-off words: each wave looks at ONE of its entries until the roles of the step before
+    // have left it (all lanes at one address: one request per look, as the flag used to be), then loads all of them and looks
+    // again until every one shows the step.  Padding days / rows are nobody's: they stay what the plain arrays hold.
+    auto fetch_tables_ll = [&](int lane, int t, int par, unsigned seq) {
+        unsigned *late = ch.late + ch.late_fatal + b;
+        const uint4 *lt = ch.llT + (size_t)b * ll_tab_len(d);
+        double v[1];
+        if (wu == 0) {
+            const uint4 *hint[1] = {lt + bx * WAVE};             // the chunk's first day: always a day of the series
+            ll_poll<1>(hint, seq, late, v);
+            const uint4 *pp[1] = {lt + min(t, d.T - 1)};
+            ll_poll<1>(pp, seq, late, v);
+            double x = v[0];
+            if ((bx + 1) * WAVE > d.T) { const double pad = LDP(w.ea + (size_t)b * d.Tp + t); x = t < d.T ? x : pad; }
+            tabbuf[lane] = x;
+        } else if (wu == 1 || (wu == 2 && ts_rows)) {
+            const int off = wu == 1 ? d.Tp : d.Tp + d.Mp;
+            const double *plain = wu == 1 ? w.eb + (size_t)b * d.Mp : w.sp + ((size_t)b * 2 + par) * d.Mp;
+            const int row = mg + min(lane, NST * TM - 1);
+            double x;
+            if (mg < d.M) {
+                const uint4 *hint[1] = {lt + off + mg};
+                ll_poll<1>(hint, seq, late, v);
+                const uint4 *pp[1] = {lt + off + min(row, d.M - 1)};
+                ll_poll<1>(pp, seq, late, v);
+                x = v[0];
+                if (mg + NST * TM > d.M) { const double pad = LDP(plain + row); x = row < d.M ? x : pad; }
+            } else {
+                x = LDP(plain + row);
+            }
+            if (lane < NST * TM) tabbuf[(wu == 1 ? TB_EB : TB_SP) + lane] = x;
+        } else if (wu == 3) {
+            const uint4 *pp[1] = {lt + d.Tp + 2 * (size_t)d.Mp};
+            ll_poll<1>(pp, seq, late, v);
+            if (lane == 0) tabbuf[TB_PSI] = v[0];
+        }
+    };
     if (fold & 1) {                                              // the start point's value: before the first step
         fetch_tables(lane0, t0, par0, true);
         __syncthreads();
@@ -1930,18 +2103,22 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
         // with it, and two of those register pairs were parked in scratch across the loop)
         int lane = lane0, t = t0, wave = wave0;
         asm volatile("" : "+v"(lane), "+v"(t), "+v"(wave));
+        // this step's number over all launches: what the tile's partial sums carry (hand-off words), and their buffer
+        const unsigned long long stepno_ = step_base + (unsigned long long)(it + 1);
+        const unsigned llseq = ll_seq(stepno_);
+        const size_t llcb = (size_t)b * 2 + (size_t)(stepno_ & 1ull);
         {
             // every wave waits (from the second step on) for the tables of this step's position, written by the roles of
             // step it-1, and fetches its share: four requests per workgroup
-            const bool fetch = wu == 0 || wu == 1 || wu == 3 || (ts_rows && wu == 2);
-            if (it > 0 && fetch) {
+            if (it > 0) {
                 __builtin_amdgcn_s_sleep(LEAP_BACKOFF);
-                leap_wait(flag2, role_base + (unsigned long long)it, ch.late + ch.late_fatal + b);
+                fetch_tables_ll(lane, t, par, ll_seq(role_base + (unsigned long long)it));
+            } else {
+                fetch_tables(lane, t, par, (fold & 1) != 0);
             }
             if (threadIdx.x == 0) { LSTAMP_MIN(0); LSTAMP_MAX(1); }
             LPROBE(0);
             LALL(0);
-            fetch_tables(lane, t, par, (fold & 1) && it == 0);
         }
         SeK sk;
         sk.load();                                               // the series' literals as scalars (device_math.h), per step
@@ -2017,7 +2194,10 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
                 for (int j = 0; j < NE; j += 2) v += src[j * LPR] + src[(j + 1) * LPR];
 #pragma unroll
                 for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, WAVE);
-                if (ss == 0 && rrow) w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + mg + st * TM + wave * RW + rr_] = v;
+                if (ss == 0 && rrow) {
+                    w.Rpart[((size_t)b * d.ntc + bx) * d.Mp + mg + st * TM + wave * RW + rr_] = v;
+                    ll_store(ch.llR + (llcb * d.ntc + bx) * d.Mp + mg + st * TM + wave * RW + rr_, v, llseq);
+                }
                 if (ts_rows) { rlbuf[st][wave][lane] = rlacc; rsbuf[st][wave][lane] = rsacc; }
             }
         }
@@ -2029,6 +2209,7 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
         for (int st = 0; st < NST; ++st) {
             const int by = byg * NST + st;
             const size_t tile = (size_t)b * d.nmt * d.ntc + (size_t)by * d.ntc + bx;
+            const size_t lltile = llcb * ((size_t)d.ntc * (d.Mp / 16)) + (size_t)by * d.ntc + bx;
             if (wave == 0) {
                 if (with_ll) {                                   // the end points only
                     const double v = wave_sum((llbuf[st][0][lane] + llbuf[st][1][lane]) + (llbuf[st][2][lane] + llbuf[st][3][lane]));
@@ -2036,24 +2217,34 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
                 }
             } else if (wave == 1) {
                 const double v = wave_sum((psibuf[st][0][lane] + psibuf[st][1][lane]) + (psibuf[st][2][lane] + psibuf[st][3][lane]));
-                if (lane == 0) w.Ppart[tile] = v;
+                if (lane == 0) { w.Ppart[tile] = v; ll_store(ch.llP + lltile, v, llseq); }
             } else if (wave == 2) {
                 const double cs = (colbuf[st][0][lane] + colbuf[st][1][lane]) + (colbuf[st][2][lane] + colbuf[st][3][lane]);
                 w.Kpart[((size_t)b * d.nmt + by) * d.Tp + t] = cs;
+                ll_store(ch.llK + (llcb * (d.Mp / 16) + by) * d.Tp + t, cs, llseq);
                 if (ts_rows) {
                     const double bs = wave_sum(cs), as = wave_sum(cs * ts_vt);
-                    if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
+                    if (lane == 0) {
+                        w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as;
+                        ll_store(ch.llTS + lltile * 4 + 0, bs, llseq); ll_store(ch.llTS + lltile * 4 + 1, as, llseq);
+                    }
                 }
             } else {
                 if (!ts_rows) {
                     const double cs = (colbuf[st][0][lane] + colbuf[st][1][lane]) + (colbuf[st][2][lane] + colbuf[st][3][lane]);
                     const double bs = wave_sum(cs), as = wave_sum(cs * ts_vt);
-                    if (lane == 0) { w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as; }
+                    if (lane == 0) {
+                        w.TS[tile * 4 + 0] = bs; w.TS[tile * 4 + 1] = as;
+                        ll_store(ch.llTS + lltile * 4 + 0, bs, llseq); ll_store(ch.llTS + lltile * 4 + 1, as, llseq);
+                    }
                 }
                 if (ts_rows) {
                     const double rl = wave_sum((rlbuf[st][0][lane] + rlbuf[st][1][lane]) + (rlbuf[st][2][lane] + rlbuf[st][3][lane]));
                     const double rs = wave_sum((rsbuf[st][0][lane] + rsbuf[st][1][lane]) + (rsbuf[st][2][lane] + rsbuf[st][3][lane]));
-                    if (lane == 0) { w.TS[tile * 4 + 2] = rl; w.TS[tile * 4 + 3] = rs; }
+                    if (lane == 0) {
+                        w.TS[tile * 4 + 2] = rl; w.TS[tile * 4 + 3] = rs;
+                        ll_store(ch.llTS + lltile * 4 + 2, rl, llseq); ll_store(ch.llTS + lltile * 4 + 3, rs, llseq);
+                    }
                 }
             }
         }
@@ -2062,10 +2253,13 @@ __device__ __forceinline__ void leap_tile(const Dims &d, const Consts &c, const 
             __syncthreads();                                     // (llbuf: nobody reads the step's LDS sums any more)
             ll_pass(w.Lpart, wave, lane);
         }
-        __syncthreads();                                         // vmcnt(0): this step's partial sums are in the XCD's L2
-        LPROBE(5);                                               // stores acknowledged
+        // The partial sums are on their way as hand-off words: nobody waits for this workgroup's count any more, except at the
+        // trajectory's end, where the roles' accept test reads Work::Lpart (plain): there the stores are acknowledged first.
+        // (No barrier otherwise: the next LDS writes are the tables', which nobody reads past the middle barrier.)
+        if (it == nsteps - 1) __syncthreads();                   // vmcnt(0)
+        LPROBE(5);
         if (threadIdx.x == 0) {
-            const unsigned long long stepno = step_base + (unsigned long long)(it + 1);
+            const unsigned long long stepno = stepno_;
             const unsigned long long old = __hip_atomic_fetch_add(cnt1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old + 1 == stepno * shard_size) __hip_atomic_store(flag1, stepno, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             LSTAMP_MIN(2); LSTAMP_MAX(3);
@@ -2143,6 +2337,8 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         const unsigned long long rstep = role_base + (unsigned long long)(it + 1);       // what the roles' flag will show
         int lane_op = lane_w;
         asm volatile("" : "+v"(lane_op));
+        LeapLL ll;
+        ll.seq_in = ll_seq(stepno); ll.seq_out = ll_seq(rstep); ll.pb = (int)(stepno & 1ull); ll.late = late;
         auto wait_tiles = [&] {
             int spins = 0;                                       // every shard's tiles are in: all of (up to) eight flags show the step
             // (the first look at once: a role that reaches its wait after the tiles -- most do, their waves get few issue slots
@@ -2163,8 +2359,7 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
                 const double *spr_ = first_ ? ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1 : w.sp + ((size_t)b * 2 + par) * d.Mp;
                 role_pregather<NTC>(d, c, spr_, role, wv, lane_op, gbuf);
             }
-            wait_tiles();
-            role_gather<NTC>(d, w, b, role, wv, lane_op, gbuf);
+            role_gather<NTC>(d, ch, ll, b, role, wv, lane_op, gbuf);   // (its loads are the wait for the tiles)
             lds_barrier();                                       // wave 0 is at its own, inside the role
             continue;
         }
@@ -2172,9 +2367,8 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         if (it > 0) leap_wait(flag2, role_base + (unsigned long long)it, late);
         RPROBE(0);                                               // the previous step's roles are done
         hmc_chunk_role<NTC, true, true>(d, c, w, s, ch, par, role, b, [&] {
-            wait_tiles();
             if (threadIdx.x == 0) { LSTAMP_MIN(4); LSTAMP_MAX(5); }
-            RPROBE(1);                                           // the step's tiles are in
+            RPROBE(1);                                           // at the wait for the step's tiles (role_gather)
         }, lane_op,
 #if defined(LEAP_STAMPS) && defined(LEAP_CPROBE)      // (the stamps INSIDE a role force its loads back early: they show the order of things, not the role's duration)
         (b == 0 && role == 0) ? ch.leap_st + ((size_t)1 * 16 + (it & 15)) * 8 :
@@ -2182,7 +2376,7 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
 #else
         nullptr,
 #endif
-        gbuf, (fin_in && it == nsteps - 1) ? 3 : (fold & 1) ? (it == 0 ? 1 : it == 1 ? 2 : 0) : 0, eps_l, it > 0);
+        gbuf, (fin_in && it == nsteps - 1) ? 3 : (fold & 1) ? (it == 0 ? 1 : it == 1 ? 2 : 0) : 0, eps_l, it > 0, ll);
         RPROBE(2);                                               // stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this role's stores are in the XCD's L2
         RPROBE(3);
@@ -2198,6 +2392,7 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         if (fin_in && it == nsteps - 1) {
             // the trajectory's end: once every role has left its parts, each makes the accept test and applies it to its entries
             leap_wait(flag2, rstep, late);
+            wait_tiles();                                        // ... and the tiles' value of the S->E term (Work::Lpart) is in the L2
             hmc_final_apply<NTC>(d, c, w, s, ch, par, role, b, lane_op);
         }
     }

@@ -1175,6 +1175,12 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     ch.late_fatal = B;
     S_HAND(ch.tail, (size_t)B * TAIL_STRIDE + (size_t)B * TAIL_FLAG_STRIDE);
     S_HAND(ch.leap, (size_t)B * LEAP_CH);
+    // k_leap's hand-off words (16 bytes per value, two step parities): the tiles' partial sums and the roles' tables
+    S_HAND(ch.llK, (size_t)B * 2 * (d.Mp / 16) * d.Tp);
+    S_HAND(ch.llR, (size_t)B * 2 * d.ntc * d.Mp);
+    S_HAND(ch.llP, (size_t)B * 2 * d.ntc * (d.Mp / 16));
+    S_HAND(ch.llTS, (size_t)B * 2 * d.ntc * (d.Mp / 16) * 4);
+    S_HAND(ch.llT, (size_t)B * ((size_t)d.Tp + 2 * (size_t)d.Mp + 8));
     S_HAND(ch.k0part, (size_t)B * ROLE_SLOTS);
     S_HAND(ch.irl0, (size_t)B);
     S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
