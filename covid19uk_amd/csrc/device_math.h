@@ -80,6 +80,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// softplus(x) as above and sigmoid(x) = d softplus / dx from the same e = exp(-|x|): 1 / (1 + e) for x >= 0, e / (1 + e) below
+// (k_hmc_chunk's roles formed it as exp(x - softplus(x)): a second exponential behind the first on the step's critical path)
+__device__ __forceinline__ double softplus_sigmoid_tab(double x, const double2 *tab, double &sig) {
+    const double e = exp(-fabs(x));
+    const double wv = 1.0 + e;
+    const double r = fast_rcp(wv);
+    sig = x >= 0.0 ? r : e * r;
+    return fmax(x, 0.0) + (fast_log(wv, tab) + (e - (wv - 1.0)) * r);
+}
+
 // Stirling with the table log (the hot kernels' form of lfact / lbinom)
 __device__ __forceinline__ double lfact(double n, const double2 *tab) {
     // small n from the LDS copy: a divergent read of the __constant__ table is a global load

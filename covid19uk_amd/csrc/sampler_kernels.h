@@ -189,6 +189,8 @@ template <int N> __device__ __forceinline__ void ll_load(const uint4 *const (&p)
 // The consumer's wait: load, look, again -- until every lane of the wave has the step's words in all N places.  Bounded like
 // every wait of k_leap (leap_wait): a time-out is counted in the chain's fatal counter, and once that is non-zero every wait
 // of the chain gives up at its next look at it; the values are then whatever was there -- the host discards the burst.
+// (Looking again at only the places that were late, one load at a time, was slower -- 140.7 us per launch against 134.7: with
+// several tiles late, each place's round trip came behind the last one's.)
 template <int N> __device__ __forceinline__ void ll_poll(const uint4 *const (&p)[N], unsigned seq, unsigned *late, double (&v)[N]) {
     u32x4 x[N];
     int spins = 0;
@@ -899,6 +901,9 @@ template <int NC> struct RoleGather {                           // offsets (doub
     static constexpr int SIZE = (4 + 2 * NC) * WAVE > (NC + 3 + 17) * WAVE ? (4 + 2 * NC) * WAVE : (NC + 3 + 17) * WAVE;
 };
 __device__ __forceinline__ int role_gather_row_wave(int kk) { return 1 + kk % 3; }     // rows of a lane by waves 1, 2, 3, 1, 2, 3, 1, 2
+// (the role's own wave takes none of them: it is the last to arrive -- with two of the six row blocks on it the launch took
+// 138.5 us against 135.1)
+__device__ __forceinline__ int role_gather_acc_wave(int kk) { return role_gather_row_wave(kk); }
 // ... and, before the wait for the tiles (but after the previous step's roles are done), the rows' spatial effects at the
 // current position for the same rows: 8 more loads past the L1 that wave 0 no longer issues on its way to the wait
 // ... and the CAR term (Q s)_m of the chunk's own rows at the current position, by the helper wave with the fewest rows to
@@ -1066,7 +1071,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
             const int nrow = (M + WAVE - 1) / WAVE;              // uniform, <= 8 (Mp <= 512)
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                if (role_gather_row_wave(kk) != wv || kk >= nrow) continue;
+                if (role_gather_acc_wave(kk) != wv || kk >= nrow) continue;
                 const int mm = lane + kk * WAVE;
                 const bool on = mm < M;
                 const uint4 *rp[NC];
@@ -1406,8 +1411,8 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
             // (that block is being rewritten by the first M-chunk of this very step)
             const double e0_ = 2.220446049250313e-16;
             const double ux_ = lane == 0 ? u0 : u1;
-            const double spx_ = softplus_tab(ux_, ltab);
-            const double sgx_ = cold_exp(ux_ - spx_);
+            double sgx_;
+            const double spx_ = softplus_sigmoid_tab(ux_, ltab, sgx_);
             psi = lane_value(spx_, 0) + e0_; sig = lane_value(spx_, 1) + e0_;
             s0 = lane_value(sgx_, 0); s1 = lane_value(sgx_, 1);
         } else {
@@ -1566,8 +1571,8 @@ __device__ __forceinline__ void hmc_chunk_role(const Dims &d, const Consts &c, c
         // both softplus in one pass: lane 0 takes u0, the other lanes u1
         const double e0 = 2.220446049250313e-16;
         const double ux = lane == 0 ? u0n : u1n;
-        const double spx = softplus_tab(ux, ltab);
-        const double sgx = cold_exp(ux - spx);             // sigmoid(u) = exp(u - softplus(u))
+        double sgx;                                        // sigmoid(u) from the same exp(-|u|) as the softplus: one exponential, not two in series
+        const double spx = softplus_sigmoid_tab(ux, ltab, sgx);
         const double psin = lane_value(spx, 0) + e0, sign = lane_value(spx, 1) + e0;
         const double s0n = lane_value(sgx, 0), s1n = lane_value(sgx, 1);
         if (probe) { asm volatile("" :: "v"(psin), "v"(sign), "v"(s0n), "v"(s1n)); }
@@ -2310,8 +2315,14 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
     const int role = role_in, b = b_in;
     if (d.nlive > 0 && bz >= d.nlive) return;
     debug_skew(d);
-    // (Raising the role waves' priority over the tile waves they share SIMDs with -- s_setprio 3, also dropped to 0 while a
-    // role only polls -- was measured and changes nothing: 0.334 - 0.335 ms per sweep in all three variants.)
+    // The role waves ahead of the tile waves they share SIMDs with: a role is one wave of serial code per step and the step ends
+    // with it, while the tiles -- since the hand-off words -- are back at their cells before the roles have finished counting
+    // in, and a wave that gets an issue slot only when three dense fp64 waves leave one took 1.5 us for its last ten instructions
+    // (141 -> 135 us per launch; measured level while the tiles still waited for the roles' flag)
+#ifndef LEAP_ROLE_PRIO
+#define LEAP_ROLE_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(LEAP_ROLE_PRIO);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane_w = (int)(threadIdx.x & 63);
     const int nsh = min(LEAP_NSH, nwg);
