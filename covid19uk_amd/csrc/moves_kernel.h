@@ -864,6 +864,52 @@ __device__ __forceinline__ void wait_token(const unsigned *p_, unsigned token, u
         if (spins > (1 << 22)) { __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // counted, no hang
     }
 }
+// Role 0's last token of a step also says which descriptor stands (Chains::mvsel): the top bit -- one round trip less for the
+// band workgroups than the token and then the word (a token is sweep * 64 + step + 1: 31 bits hold 33 million sweeps)
+__device__ __forceinline__ unsigned wait_token_flag(const unsigned *p_, unsigned token, unsigned *late) {
+    int spins = 0;
+    unsigned v;
+    while (((v = ld_l2(p_)) & 0x7fffffffu) != token) {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if ((spins & 255) == 0 && ld_l2(late) != 0u) break;
+        if (spins > (1 << 22)) { __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    return v >> 31;
+}
+// A proposal descriptor as hand-off words (sampler_kernels.h): 60 dwords in 30 words {dword, token, dword, token}.  The band
+// workgroups used to wait for role 1's token (after its stores were acknowledged) and then copy the descriptor -- two round
+// trips behind each other; now lanes 0..29 of one wave look at their word until it shows the launch's token.
+constexpr int MOVE_LLW = (MOVE_DW + 1) / 2;
+static_assert(MOVE_LLW <= 32, "Chains::llmv holds 32 words per descriptor");
+__device__ __forceinline__ void move_store_ll(uint4 *dst, const Move *src_lds, int lane, unsigned token) {
+    if (lane < MOVE_LLW) {
+        const int *sd = reinterpret_cast<const int *>(src_lds);
+        uint4 x;
+        x.x = (unsigned)sd[2 * lane]; x.y = token;
+        x.z = 2 * lane + 1 < MOVE_DW ? (unsigned)sd[2 * lane + 1] : 0u; x.w = token;
+        dst[lane] = x;
+    }
+}
+__device__ __forceinline__ void move_wait_ll(Move *dst_lds, const uint4 *src, int lane, unsigned token, unsigned *late) {
+    // (one wave; every lane looks at a word -- the lanes beyond the descriptor at its last one)
+    const uint4 *pp[1] = {src + min(lane, MOVE_LLW - 1)};
+    u32x4 x[1];
+    int spins = 0;
+    for (;;) {
+        ll_load<1>(pp, x);
+        if (__builtin_amdgcn_ballot_w64(!ll_ok(x[0], token)) == 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if ((spins & 255) == 0 && ld_l2(late) != 0u) break;
+        if (spins > (1 << 22)) { if (lane == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    if (lane < MOVE_LLW) {
+        int *dd = reinterpret_cast<int *>(dst_lds);
+        dd[2 * lane] = (int)x[0].x;
+        if (2 * lane + 1 < MOVE_DW) dd[2 * lane + 1] = (int)x[0].z;
+    }
+}
 // SOLO (k_move_pairs): the workgroup has its CU to itself and its L1 was emptied when the step began, so what it loads of
 // the planes AFTER the token that declares them final cannot be an older copy: plain loads, which a wave issues back to
 // back, where the launch-per-pair form (other workgroups of the chain may share the CU and its L1) reads past the L1
@@ -915,15 +961,19 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     // 5), a little before it has certified the speculative proposal; the band is evaluated for that proposal at once
     // and, in the rare launch in which a row conflict made the authoritative role draw it again (Chains::mvsel, known
     // with the last token), evaluated again for the re-drawn one.
-    if (tid == 0) {
-        wait_token(done + 5, token, ch.late + ch.late_fatal + b);
-        // the speculative role publishes its descriptor (token 3) well before it is done (token 1)
-        if (has_r1) wait_token(done + 3, token, ch.late + ch.late_fatal + b);
+    if (tid == 0) wait_token(done + 5, token, ch.late + ch.late_fatal + b);
+    if (has_r1) {
+        // the speculative role publishes its descriptor as hand-off words well before it is done (token 1): wave 1 looks for
+        // them while thread 0 waits for the planes
+        if (wave == 1) move_wait_ll(&mvA, ch.llmv + ((size_t)buf * s.B + b) * 32, lane, token, ch.late + ch.late_fatal + b);
+        QSTAMP(st_slot, st_step, 2);
+        __syncthreads();
+    } else {
+        QSTAMP(st_slot, st_step, 2);
+        __syncthreads();
+        move_copy_l2(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
+        __syncthreads();
     }
-    QSTAMP(st_slot, st_step, 2);
-    __syncthreads();
-    move_copy_l2(&mvA, ch.mv + (size_t)buf * s.B + b, 0);
-    __syncthreads();
     auto evaluate = [&](const Move &mv) -> double {
         double dth = 0.0;
         if (mv.valid && mv.n > 0 && mv.any_dI) {
@@ -982,10 +1032,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     };
     double dth = evaluate(mvA);
     QSTAMP(st_slot, st_step, 3);
-    if (tid == 0) {
-        wait_token(done + 0, token, ch.late + ch.late_fatal + b);
-        mv_sel = ld_l2(ch.mvsel + (size_t)buf * s.B + b);
-    }
+    if (tid == 0) mv_sel = (int)wait_token_flag(done + 0, token, ch.late + ch.late_fatal + b);   // (Chains::mvsel rides on the token)
     __syncthreads();
     if (mv_sel) {                                          // uniform, rare
         move_copy_l2(&mvB, ch.mvfix + (size_t)buf * s.B + b, 64);
@@ -1288,12 +1335,10 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
         RSTAMP(10);
         Move *out = (role == 1 ? ch.mv : ch.mvs) + (size_t)(pbuf ^ 1) * s.B + b;
         move_copy(out, &sm_nx.mv, MVB - WAVE);             // by the last wave: nobody's loads queue behind the store
-        if (nband > 0 && role == 1 && tid >= MVB - WAVE) {
-            // band workgroups start from this descriptor while the log-ratio over the updated rows is still being evaluated
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == MVB - WAVE)
-                __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 3, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // band workgroups start from this descriptor while the log-ratio over the updated rows is still being evaluated: as
+        // hand-off words, which need neither the acknowledgement of the stores nor a token
+        if (nband > 0 && role == 1 && tid >= MVB - WAVE)
+            move_store_ll(ch.llmv + ((size_t)(pbuf ^ 1) * s.B + b) * 32, &sm_nx.mv, tid - (MVB - WAVE), token);
         // ... and its log-ratio over the rows it updates (for role 1, k_move_delta then does the band only); the F
         // band of an accepted pending update is not in F yet and is added on the fly
         const Move *fpp = (pend_acc && pendp->any_dI) ? pendp : nullptr;
@@ -1506,8 +1551,9 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
     }
     if (nband > 0) {                                       // band workgroups may go: descriptors, mvsel and fpend are in L2
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 0, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0)                                      // (which descriptor stands -- Chains::mvsel -- in the token's top bit)
+            __hip_atomic_store(ch.done + (size_t)b * 2 * TAIL_STRIDE + 0, token | ((do_nx && s_conf) ? 0x80000000u : 0u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -117,6 +117,8 @@ struct Chains {
     uint4 *llTS;                                         // [B][2][ntc Mp/16][4] tile scalars (Work::TS)
     uint4 *llT;                                          // [B][Tp + 2 Mp + 8]  ... and what the roles leave for the tiles: exp(a_t) | exp(b_m)/N_m |
                                                          //     spatial effects | psi (Work::ea, eb, sp, scal[SC_PSI])
+    uint4 *llmv;                                         // [2][B][32] k_move_pair(s) with band workgroups: role 1's proposal descriptor (Chains::mv)
+                                                         //     as hand-off words, two dwords apiece, numbered by the launch's token
     unsigned *hand2;                                     // [B] the same token for role 2 (pre-drawn S->E-type proposal)
     Move *mvs;                                           // [2][B] S->E-type proposal pre-drawn for the next launch (k_move_pair, role 2)
     double *DownS;                                       // [2][B][2] its own-rows log-ratio {theta, const}

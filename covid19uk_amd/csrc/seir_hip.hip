@@ -1181,6 +1181,7 @@ extern "C" int seir_sampler_create(seir_ctx *ctx, const seir_sampler_desc *ds, s
     S_HAND(ch.llP, (size_t)B * 2 * d.ntc * (d.Mp / 16));
     S_HAND(ch.llTS, (size_t)B * 2 * d.ntc * (d.Mp / 16) * 4);
     S_HAND(ch.llT, (size_t)B * ((size_t)d.Tp + 2 * (size_t)d.Mp + 8));
+    S_HAND(ch.llmv, (size_t)2 * B * 32);
     S_HAND(ch.k0part, (size_t)B * ROLE_SLOTS);
     S_HAND(ch.irl0, (size_t)B);
     S_ALLOC(ch.leap_st, (size_t)(B + 2) * 16 * 8 + 4096);
