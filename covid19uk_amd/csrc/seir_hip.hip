@@ -1609,33 +1609,45 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         }
         return (long long)slot;
     };
+    // chains per launch of k_leap: all of them -- or, for 16 chains, which do not fit the chip at once, two launches of 8 one
+    // after the other (2 x 134 us at UK-380 against 335 us for the 18 launches of the per-step form; from 24 chains on the
+    // per-step form is the faster one)
+    int leap_nbv = nbv_all;
     if (chunked && s->hmc_leap && s->hmc_tail && s->xcd_local && s->ngroups == 1 && (l.affinity & 1) && !s->use_graph &&
         xcd_affinity_applies(ntile_all, nbv_all) && (d0.ntc == 1 || d0.ntc == 6 || d0.ntc == 12) && c.L >= 3 && d0.nmt <= WAVE &&
         d0.nmt % 2 == 0) {
         const int ti = ts_mode - 1, ni = d0.ntc == 1 ? 0 : d0.ntc == 6 ? 1 : 2;
         const int nmt24 = d0.Mp / 24, wgs24 = d0.ntc * nmt24;
-        if (s->leap_rows != 32 && ts_mode == 1 && d0.ntc == 6 && d0.Mp % 24 == 0 && xcd_affinity_applies(wgs24, nbv_all) &&
-            (long long)(wgs24 + per_roles) * nbv_all <= leap_slots(ti, ni, 1)) {
-            leap_ok = true;
-            leap_nst = 1; leap_nmt = nmt24; leap_wgs = wgs24;
-        } else if (s->leap_rows != 24) {
-            leap_ok = (long long)(ntile_all / 2 + per_roles) * nbv_all <= leap_slots(ti, ni, 2);
-        }
+        auto fit = [&](int nbv) {
+            if (s->leap_rows != 32 && ts_mode == 1 && d0.ntc == 6 && d0.Mp % 24 == 0 && xcd_affinity_applies(wgs24, nbv) &&
+                (long long)(wgs24 + per_roles) * nbv <= leap_slots(ti, ni, 1)) {
+                leap_nst = 1; leap_nmt = nmt24; leap_wgs = wgs24;
+                return true;
+            }
+            if (s->leap_rows != 24) return (long long)(ntile_all / 2 + per_roles) * nbv <= leap_slots(ti, ni, 2);
+            return false;
+        };
+        leap_ok = fit(nbv_all);
+        if (!leap_ok && nb == 16 && fit(8)) { leap_ok = true; leap_nbv = 8; }
     }
     auto launch_leap = [&](int par0, int nsteps, int fold) {
         Dims df = l.d;
-        df.aff_nb = nbv_all;
-        df.nlive = nbv_all != nb ? nb : 0;
+        df.aff_nb = leap_nbv;
+        df.nlive = leap_nbv == nbv_all && nbv_all != nb ? nb : 0;
         df.sp_par = 0;
         df.chunked = ts_mode;
         df.nmt = leap_nmt;                                       // the partial sums of this launch: one set per row tile of ITS shape
-        const dim3 gf((unsigned)((leap_wgs + per_roles) * nbv_all));
+        const dim3 gf((unsigned)((leap_wgs + per_roles) * leap_nbv));
+        // (every chain's counters and hand-off words count its OWN launches: the sub-batches of a sweep share the step numbers)
         const unsigned long long step_base = s->leap_steps, role_base = s->leap_rsteps;
         s->leap_steps += (unsigned long long)nsteps;
         s->leap_rsteps += (unsigned long long)(nsteps - (((fold & 2) && !(fold & 4)) ? 1 : 0));
-        void *args[] = {(void *)&df, (void *)&ctx->c, (void *)&ctx->w, (void *)&c, (void *)&s->ch, (void *)&par0, (void *)&nsteps,
-                        (void *)&step_base, (void *)&role_base, (void *)&fold};
-        (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, leap_nst), gf, dim3(256), args, 0, st);
+        for (int sub = 0; sub < nbv_all / leap_nbv; ++sub) {
+            df.b0 = l.d.b0 + sub * leap_nbv;
+            void *args[] = {(void *)&df, (void *)&ctx->c, (void *)&ctx->w, (void *)&c, (void *)&s->ch, (void *)&par0, (void *)&nsteps,
+                            (void *)&step_base, (void *)&role_base, (void *)&fold};
+            (void)hipLaunchKernel(leap_fn(ts_mode, d0.ntc, leap_nst), gf, dim3(256), args, 0, st);
+        }
     };
     const bool prof0 = s->prof_i >= 0 && (size_t)(2 * s->prof_i + 1) < s->prof_ev.size() && g == 0;
     const bool fold = leap_ok && s->hmc_fold;
@@ -1656,7 +1668,7 @@ static void enqueue_sweep(seir_sampler *s, int g) {
         if (prof0) {
             (void)hipEventRecord(s->prof_ev[2 * s->prof_i + 1], st);
             s->prof_i += 1;
-            s->prof_launches = 1;
+            s->prof_launches = nbv_all / leap_nbv;
             s->prof_evals = c.L + 1;
         }
         if (!s->hmc_end) {

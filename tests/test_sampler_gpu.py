@@ -670,11 +670,12 @@ def test_chunk_roles_inside_the_gradient_launch_give_the_same_bits(api, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,B,eps", [("uk380", 8, 1.2e-5), ("uk380", 3, 1.2e-5), ("slow_520x60", 2, 3e-5), ("micro_17x70", 8, 0.0004),
-                                        ("micro_20x60", 8, 0.0004)])
+@pytest.mark.parametrize("name,B,eps", [("uk380", 8, 1.2e-5), ("uk380", 3, 1.2e-5), ("uk380", 16, 1.2e-5), ("slow_520x60", 2, 3e-5),
+                                        ("micro_17x70", 8, 0.0004), ("micro_20x60", 8, 0.0004)])
 def test_leapfrog_launch_forms_agree_at_size(api, name, B, eps):
     """The same comparison where the persistent launch has something to get wrong: the headline size (72 tile workgroups
-    and 12 four-wave roles per chain, six day chunks, eight counter shards), a partial layout of 8, and M > 512 (the tiles
+    and 12 four-wave roles per chain, six day chunks, eight counter shards), a partial layout of 8, 16 chains (the persistent
+    launch as two launches of 8 chains one after the other: they share the step numbers), and M > 512 (the tiles
     also form the row scalars: the second instance of the kernels).  Three sweeps with all updates on; "chunk-leap" is the
     persistent launch for the inner steps alone, "chunk-stage" the one that also carries the trajectory's first step and both
     end-point gradients, "chunk" the whole trajectory (last half kick, accept test, adaptation and trace by the roles too)."""
