@@ -915,7 +915,9 @@ __device__ __forceinline__ void move_wait_ll(Move *dst_lds, const uint4 *src, in
 // back, where the launch-per-pair form (other workgroups of the chain may share the CU and its L1) reads past the L1
 template <bool SOLO, typename TT>
 __device__ __forceinline__ TT ld_band(const TT *p_) { return SOLO ? *p_ : ld_l2(p_); }
-template <bool SOLO>
+// NRB: rows per wave of a band workgroup -- 2 (16 rows per workgroup: 24 of them per chain at UK-380, one chain per XCD) or 4 (32
+// rows: 12 per chain, so that (3 + 12) x 16 workgroups -- sixteen chains, two per XCD -- still hold one CU each)
+template <bool SOLO, int NRB>
 __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, const Work &w, const SamplerCfg &s,
                                                 const Chains &ch, int b, int bx, int nband, unsigned token, bool has_r1,
                                                 bool has_r2, int buf, int st_slot = 0, int st_step = 0) {
@@ -941,12 +943,16 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     move_copy_l2(&fp, ch.fpend + b, 128);
     __syncthreads();
     const bool has_fp = fp.valid == 1;
-    constexpr int NRB = 2, NPF = 2;                    // rows per wave (rpb <= 16), 64-day pieces of a hull (dmax <= 127)
-    double cfb[NRB][MMAX], Fpre[NRB][NPF];
+    constexpr int NPF = 2;                             // 64-day pieces of a hull (dmax <= 127); rows per wave: NRB (rpb <= 8 NRB)
+    // (prefetched for two rows per wave; with four the sixteen coefficients and eight F values per lane held across the
+    // evaluation put the persistent launch into scratch: there they are formed where they are used)
+    constexpr bool PREF = NRB == 2;
+    constexpr int NRP = PREF ? NRB : 1;
+    double cfb[NRP][MMAX], Fpre[NRP][NPF];
 #pragma unroll
-    for (int r = 0; r < NRB; ++r) {
+    for (int r = 0; r < NRP; ++r) {
         const int j = r_lo + wave + r * MVW;
-        const bool onr = has_fp && j < r_hi;
+        const bool onr = PREF && has_fp && j < r_hi;
 #pragma unroll
         for (int i = 0; i < MMAX; ++i)
             cfb[r][i] = (onr && i < fp.n) ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
@@ -956,7 +962,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
             Fpre[r][q] = (onr && t <= fp.HI) ? ld_band<SOLO>(w.F + ((size_t)b * d.Mp + j) * d.Tp + t) : 0.0;
         }
     }
-    const bool pre_ok = !has_fp || fp.HI - fp.LO < NPF * WAVE;      // a longer hull (dmax > 127): the loop at the end reloads
+    const bool pre_ok = PREF && (!has_fp || fp.HI - fp.LO < NPF * WAVE);   // a longer hull (dmax > 127): the loop at the end reloads
     // ---- the proposal to evaluate.  The planes are final once the authoritative role has applied its own updates (token
     // 5), a little before it has certified the speculative proposal; the band is evaluated for that proposal at once
     // and, in the rare launch in which a row conflict made the authoritative role draw it again (Chains::mvsel, known
@@ -977,16 +983,18 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     auto evaluate = [&](const Move &mv) -> double {
         double dth = 0.0;
         if (mv.valid && mv.n > 0 && mv.any_dI) {
-            // a wave's two rows (rpb <= 16 = 2 MVW) side by side: the coefficients of both, then per 64-day piece of the hull
+            // a wave's rows two by two, side by side: the coefficients of both, then per 64-day piece of the hull
             // the loads of both before any arithmetic -- half the dependent round trips of one row after the other
             const double *ea = w.ea + (size_t)b * d.Tp;
             constexpr int NR = 2;
+    #pragma unroll 1
+            for (int r0 = 0; r0 < NRB; r0 += NR) {
             int jr[NR];
             bool on[NR];
             double eb[NR], coef[NR][MMAX], cfp[NR][MMAX];
     #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                jr[r] = r_lo + wave + r * MVW;
+                jr[r] = r_lo + wave + (r0 + r) * MVW;
                 bool mine = false;
     #pragma unroll
                 for (int i = 0; i < MMAX; ++i) mine |= (i < mv.n && mv.m[i] == jr[r]);
@@ -996,7 +1004,9 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     #pragma unroll
                 for (int i = 0; i < MMAX; ++i) {
                     coef[r][i] = (on[r] && i < mv.n) ? c.Cstar[(size_t)mv.m[i] * d.Kp0 + j] * c.invN[mv.m[i]] * (double)(-mv.dsrc[i]) : 0.0;
-                    cfp[r][i] = on[r] ? cfb[r][i] : 0.0;   // the accepted update's coefficients: prefetched above for the same rows
+                    // the accepted update's coefficients: prefetched above for the same rows (two rows per wave), or formed here
+                    if (PREF) cfp[r][i] = on[r] ? cfb[PREF ? r : 0][i] : 0.0;
+                    else cfp[r][i] = (has_fp && on[r] && i < fp.n) ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
                 }
             }
             for (int t0 = mv.LO; t0 <= mv.HI; t0 += WAVE) {
@@ -1026,6 +1036,7 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
                     }
                     dth += band_delta(S[r], I[r], kse[r], F[r], dF[r], ea[t] * eb[r], psi * c.W[t], d.rate_floor * d.dt, d.dt, ltab);
                 }
+            }
             }
         }
         return dth;
@@ -1064,6 +1075,12 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
         const int j = r_lo + wave + r * MVW;
         if (j >= r_hi) continue;
         double *Fr = w.F + ((size_t)b * d.Mp + j) * d.Tp;
+        double cfr[MMAX];                                  // this row's coefficients: the prefetched ones, or formed now
+#pragma unroll
+        for (int i = 0; i < MMAX; ++i) {
+            if (PREF) cfr[i] = cfb[PREF ? r : 0][i];
+            else cfr[i] = i < fp.n ? c.Cstar[(size_t)fp.m[i] * d.Kp0 + j] * c.invN[fp.m[i]] * (double)(-fp.dsrc[i]) : 0.0;
+        }
         if (pre_ok) {
 #pragma unroll
             for (int q = 0; q < NPF; ++q) {
@@ -1071,15 +1088,15 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
                 double dFp = 0.0;
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)
-                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfb[r][i];
-                if (t <= fp.HI && dFp != 0.0) Fr[t] = Fpre[r][q] + dFp;
+                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfr[i];
+                if (t <= fp.HI && dFp != 0.0) Fr[t] = Fpre[PREF ? r : 0][q] + dFp;
             }
         } else {
             for (int t = fp.LO + lane; t <= fp.HI; t += WAVE) {
                 double dFp = 0.0;
 #pragma unroll
                 for (int i = 0; i < MMAX; ++i)
-                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfb[r][i];
+                    if (i < fp.n && t > fp.lo[i] && t <= fp.hi[i]) dFp += cfr[i];
                 if (dFp != 0.0) Fr[t] = ld_band<SOLO>(Fr + t) + dFp;
             }
         }
@@ -1188,7 +1205,10 @@ __device__ __forceinline__ void pair_step(const Dims &d, const Consts &c, const 
         }
         const unsigned tok = ch.sweep[b] * 64u + (unsigned)lidx + 1u;
         const bool r1 = next.kind >= 0 && nroles >= 2, r2 = se_next.kind >= 0 && nroles == 3;
-        pair_band_block<SOLO>(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1, slot, lidx);
+        if ((d.M + nband - 1) / nband > 2 * MVW)              // (uniform) more than 16 rows per band workgroup: four per wave
+            pair_band_block<SOLO, 4>(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1, slot, lidx);
+        else
+            pair_band_block<SOLO, 2>(d, c, w, s, ch, b, slot - nroles, nband, tok, r1, r2, pbuf ^ 1, slot, lidx);
         return;
     }
     const int role = slot == nroles - 1 ? 0 : slot + 1;

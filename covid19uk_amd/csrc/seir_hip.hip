@@ -1843,8 +1843,11 @@ static void enqueue_sweep(seir_sampler *s, int g) {
             int have_pre = 0;
             int cus = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-            const int nband_fit = (d.M + 15) / 16;                      // 16 rows per band workgroup: two per wave
             const int nbv = (nb + 7) / 8 * 8;                            // as for k_se_chunk: the layout's chains
+            // 16 rows per band workgroup, two per wave; 32 (four per wave) where that is what lets every workgroup of the launch
+            // hold a CU: sixteen chains at UK-380 are (3 + 12) x 16 = 240 workgroups
+            int nband_fit = (d.M + 15) / 16;
+            if ((3 + nband_fit) * nbv > cus && (3 + (d.M + 31) / 32) * nbv <= cus) nband_fit = (d.M + 31) / 32;
             const bool band_in_pair = s->moves_mode != 3 && s->xcd_local && nbv > 0 && s->ngroups == 1 && !s->use_graph &&
                                       (3 + nband_fit) * nbv <= cus;
             const int nbk = band_in_pair ? nbv : nb;

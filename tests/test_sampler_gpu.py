@@ -792,7 +792,9 @@ def test_trajectory_end_inside_the_launch_accepts_rejects_and_adapts_like_the_st
                                             ("uk380", 2, dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5),
                                             ("ni11", 11, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
                                             ("ni11", 16, dict(dmax=10, nmax=5, m=2, occult_nmax=5, num_event_time_updates=3), 0.02),
-                                            ("uk380", 8, dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5)])
+                                            ("uk380", 8, dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5),
+                                            # sixteen chains, two per XCD: 12 band workgroups of 32 rows (four per wave) per chain
+                                            ("uk380", 16, dict(dmax=84, nmax=25, m=2, occult_nmax=15, num_event_time_updates=5), 1.2e-5)])
 def test_band_workgroups_inside_the_pair_launch_give_the_same_bits(api, name, B, cfg, eps):
     """moves="paired" with a multiple of 8 chains whose workgroups all fit the chip at once evaluates the band part of the E->I-type log-ratio with more workgroups of the
     k_move_pair launch (pair_band_block: done-tokens and an XCD-local hand-off, the F band of the update accepted in
