@@ -217,7 +217,8 @@ typedef struct {
                                        once; else one launch per step with the chunk roles inside the gradient launch
                                        (k_se_chunk; needs the XCD placement only) between the stage kernels
                                        (k_hmc_step<0>, <2>); else the chunks as their own launch (k_hmc_chunk).
-                                       Where the persistent launch does not fit (16+ chains at UK-380, SYN-2048) mode 0 runs
+                                       Sixteen chains run it as two launches of eight, one after the other.
+                                       Where the persistent launch does not fit (24+ chains at UK-380, SYN-2048) mode 0 runs
                                        as 6: the whole trajectory as L + 1 per-step launches (k_se_chunk) whose chunk roles also
                                        do the trajectory's first step and last half kick, and k_hmc_final (the accept test,
                                        adaptation and trace by the roles) -- no single-workgroup stage kernel.
