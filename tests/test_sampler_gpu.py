@@ -510,6 +510,42 @@ def test_chains_are_independent_of_batch_composition(api):
     assert np.array_equal(tr_all.hmc["target_log_prob"][:, 2], tr_one.hmc["target_log_prob"][:, 0])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [8, 16])
+def test_handoffs_of_the_persistent_launches_do_not_depend_on_timing(api, B):
+    """k_leap hands partial sums and tables from workgroup to workgroup as self-validating 16-byte words (value + step number in
+    both halves, no acknowledgement, no flag), k_move_pairs its proposal descriptor; at 16 chains the leapfrog launch runs as two
+    launches of 8 that share the step numbers.  Three hundred sweeps at the headline size from one seed, the second run with the
+    workgroups' start skewed: a torn or stale word, a missed wait or a race between steps shows as a difference in the bits --
+    and no wait may time out.  (tools/dev/ll_soak.py is the long form: 5 000 sweeps, three skews.)"""
+    SeirModel, ChainSampler = api
+    case = H.build_case("uk380", 43, alpha_t_sd=0.005)
+    u = synth.jitter_params(case["u"], B, scale=0.002, seed=3, T=case["k"].T)
+    ev = np.stack([case["events"]] * B)
+    out = []
+    for skew in (0, 3):
+        with SeirModel(case["cov"], case["init"], max_chains=B) as model:
+            model.set_option(debug_skew=skew)
+            with ChainSampler(model, CFG_REF, B, seed=21, trace_capacity=100, record_events=False) as s:
+                if not s.xcd_local():
+                    pytest.skip("this GPU does not place block ids congruent mod 8 on one XCD: the persistent forms are not used")
+                s.set_state(u, ev)
+                s.set_kernel(step_size=1.2e-5)
+                for _ in range(3):
+                    s.reset_trace()
+                    s.run(100)
+                tr = s.read_trace(100, events=False)
+                assert not s.pair_timeouts().any()
+                out.append((s.get_state(), tr))
+    (q0, e0, l0), t0 = out[0]
+    (q1, e1, l1), t1 = out[1]
+    assert np.array_equal(q0, q1) and np.array_equal(e0, e1) and np.array_equal(l0, l1)
+    assert np.array_equal(t0.theta, t1.theta)
+    for k in t0.hmc:
+        assert np.array_equal(t0.hmc[k], t1.hmc[k]), k
+    assert t0.hmc["is_accepted"].any() and sum(int(v["is_accepted"].sum()) for v in t0.moves.values()) > 0
+
+
 @pytest.mark.parametrize("B,groups,affinity,graph", [(8, 1, 3, 0), (8, 1, 0, 0), (3, 1, 3, 0), (16, 1, 3, 0),
                                                     (8, 2, 3, 0), (6, 4, 3, 0), (8, 1, 3, 1), (6, 2, 3, 1)])
 def test_launch_geometries_give_identical_chains(api, B, groups, affinity, graph):
