@@ -202,7 +202,10 @@ template <int N> __device__ __forceinline__ void ll_poll(const uint4 *const (&p)
 #pragma unroll
         for (int j = 0; j < N; ++j) ok = ok && ll_ok(x[j], seq);
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-        __builtin_amdgcn_s_sleep(2);
+#ifndef LL_POLL_SLEEP
+#define LL_POLL_SLEEP 2
+#endif
+        __builtin_amdgcn_s_sleep(LL_POLL_SLEEP);
         ++spins;
         if ((spins & 63) == 0 && __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         if (spins > (1 << 19)) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -1885,7 +1888,10 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
 // Every wait is bounded; a time-out is counted in Chains::late (fatal part) and the workgroup goes on, so the grid
 // always drains.
 // ---------------------------------------------------------------------------------------------
-constexpr int LEAP_BACKOFF = 12;     // x 64 cycles slept before a tile first looks for the roles' flag
+#ifndef LEAP_BACKOFF_N
+#define LEAP_BACKOFF_N 12
+#endif
+constexpr int LEAP_BACKOFF = LEAP_BACKOFF_N;     // x 64 cycles slept before a tile first looks for the roles' tables
 constexpr int LEAP_NSH = 8;          // counters / flag copies per chain, 128 bytes apart
 constexpr int LEAP_CH = 1024;        // 64-bit words of Chains::leap per chain
 #define LEAP_CNT1(b_, k_) (ch.leap + (size_t)(b_) * LEAP_CH + (k_) * 16)            // tiles counted in on shard k, over all launches
@@ -2325,6 +2331,9 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
 #define LEAP_ROLE_PRIO 3
 #endif
     __builtin_amdgcn_s_setprio(LEAP_ROLE_PRIO);
+#ifdef LEAP_HELPER_PRIO                            // (developer builds: the helper waves at another priority than the role's own)
+    if ((threadIdx.x >> 6) != 0) __builtin_amdgcn_s_setprio(LEAP_HELPER_PRIO);
+#endif
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane_w = (int)(threadIdx.x & 63);
     const int nsh = min(LEAP_NSH, nwg);
