@@ -1789,8 +1789,12 @@ constexpr int TAIL_BACKOFF = 30;     // x 64 cycles
 // counters' (stride 16) the polls still cost 6 us per sweep -- presumably the same L2 channel
 constexpr int TAIL_FLAG_STRIDE = 528;
 #define TAIL_FLAG_AT(B_, b_) ((size_t)(B_) * TAIL_STRIDE + (size_t)(b_) * TAIL_FLAG_STRIDE)
+#ifndef SE_CHUNK_WAVES12
+#define SE_CHUNK_WAVES12 3
+#endif
+constexpr int se_chunk_waves(int tsm, int ntc) { return ntc == 12 ? SE_CHUNK_WAVES12 : tsm == 2 ? 3 : 4; }
 template <int TSM, int NTC>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, se_chunk_waves(TSM, NTC))
 void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsigned long long target, int traj) {
     const int ntile = d.ntc * d.nmt, n_tiles = ntile * d.aff_nb;
     if ((int)blockIdx.x < n_tiles) {

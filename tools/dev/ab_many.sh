@@ -3,7 +3,7 @@ mkdir -p gpurun_out/r04
 out=gpurun_out/r04/ab_many.txt; : > $out
 for rep in 0 1 2; do
   for v in "$@"; do
-    timeout -k 10 200 python tools/dev/leap_variant.py $v ${AB_CHAINS:-8} 300 2>/dev/null >> $out
+    timeout -k 10 300 python tools/dev/leap_variant.py $v ${AB_CHAINS:-8} ${AB_SWEEPS:-300} ${AB_WORKLOAD:-uk380} 2>/dev/null >> $out
   done
 done
 cat $out
