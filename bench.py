@@ -110,6 +110,19 @@ def alg_bytes_per_eval(M, T, P, B):
     return B * (24 * M * T + 8 * (4 * M + 3 * T + P) + 8 + 8 * P) + 8 * M * M
 
 
+def leap_section_name(launches, evals):
+    """What ran between the events of seir_sampler_time_leapfrog, from its launch and evaluation counts (include/seir_hip.h)."""
+    if launches == 1:
+        return "k_leap (persistent: the whole HMC trajectory)"
+    if launches == 2 and evals > 2:
+        return "k_leap x 2 (persistent: the whole HMC trajectory, two launches of 8 chains one after the other)"
+    if launches == evals + 1:
+        return "k_se_chunk x (L+1) + k_hmc_final (one launch per gradient evaluation: tiles + chunk roles; the accept test by the roles' own launch)"
+    if launches == evals:
+        return "k_se_chunk (one launch per inner leapfrog step: gradient tiles + chunk roles)"
+    return "k_se + k_hmc_chunk (two launches per inner leapfrog step)"
+
+
 def aux_config(label, workload, B, local, seed, steps, warm, eps, f32=False):
     """One of BASELINE.json's other configurations on this GPU, beside the headline: `steps` timed sweeps of B chains after
     `warm` untimed ones (HIP events on the context stream, inputs resident, draws recorded to the burst buffer), the sweep's
@@ -149,8 +162,7 @@ def aux_config(label, workload, B, local, seed, steps, warm, eps, f32=False):
                 "all_log_probs_finite": bool(np.isfinite(tr.hmc["target_log_prob"]).all()),
                 "launch_form": list(s.launch_form()), "recoveries": len(s.recoveries),
                 "dominant_kernel": {
-                    "kernel": ("k_leap (persistent: the whole HMC trajectory)" if ll == 1 else
-                               "k_se_chunk (one launch per inner leapfrog step)" if ll == le else "k_se + k_hmc_chunk"),
+                    "kernel": leap_section_name(ll, le),
                     "launches_per_sweep": ll, "gradient_evaluations": le, "section_us": 1e3 * lm,
                     "share_of_sweep": lm / (ms / steps), "bound": "hbm",
                     "achieved": le * alg / (lm * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -608,14 +620,12 @@ def main():
                        "sweep": "HMC(16 leapfrogs) + 5 x [S->E move, E->I move, S->E occult, E->I occult]",
                        "mcmc": MCMC_CONFIG, "draws_recorded": "theta + events[M,T,3] (uint16 counts) + kernel results per sweep",
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"kernel": (f"k_leap<TSM,NTC,2> (persistent: {leap_evals} of the sweep's 17 gradient evaluations in one launch -- the "
+            "roofline": {"kernel": (f"k_leap<TSM,NTC,NST,RW> (persistent: {leap_evals} of the sweep's 17 gradient evaluations in one launch -- the "
                                     "whole HMC trajectory: per evaluation the S->E term's gradient sums of all chains "
                                     "from register-resident cells (and its value at the two end points), then the chunk roles' leapfrog "
                                     "update; at the end the roles' last half kick, accept test, adaptation and trace)")
                                    if leap_launches == 1 else
-                                   (f"k_se_chunk (one launch per inner leapfrog step: gradient tiles + chunk roles; {leap_evals} of the sweep's 17 "
-                                    "gradient evaluations)" if leap_launches == leap_evals else
-                                    f"k_se + k_hmc_chunk (two launches per inner leapfrog step; {leap_evals} of the sweep's 17 gradient evaluations)"),
+                                   f"{leap_section_name(leap_launches, leap_evals)}; {leap_evals} of the sweep's 17 gradient evaluations",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          # `frac` above is the contract's figure: ALGORITHMIC bytes / duration / peak.  It is not a utilisation
@@ -623,7 +633,8 @@ def main():
                          # readings are also given under names that say what they are:
                          "frac_algorithmic_bytes": achieved / HBM_PEAK_GBPS,
                          "frac_measured_traffic": (traffic / (leap_ms * 1e-3 / leap_launches) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "limited_by": ("fp64 vector issue of the tile phase + two in-L2 hand-offs per leapfrog step (latency), not bandwidth"
+                         "limited_by": ("the chunk roles' serial part of a leapfrog step (one wave per role: gather, sums, exponentials) and the tiles' fp64 vector "
+                                        "issue, joined by two hand-offs through the XCD's L2 (self-validating words): latency, not bandwidth"
                                         if leap_launches == 1 else "HBM / fabric streaming of the planes, then role latency"),
                          "frac_uses": "algorithmic bytes of SURVEY.md 8d (fp64 events + vectors per chain, Cstar once) x the gradient "
                                       "evaluations the timed section performs / its duration (HIP events around it in ordinary sweeps)",
