@@ -1826,6 +1826,11 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
         return;
     }
     if (threadIdx.x >= WAVE) return;                   // a role is one wave
+#ifndef SE_CHUNK_ROLE_PRIO
+#define SE_CHUNK_ROLE_PRIO 3
+#endif
+    // ... of serial code, on SIMDs it shares with the tile waves of chains that are still at their cells: ahead of them (as k_leap's)
+    __builtin_amdgcn_s_setprio(SE_CHUNK_ROLE_PRIO);
     const int L = (int)blockIdx.x - n_tiles;
     const int bz = L % d.aff_nb, role = L / d.aff_nb, b = d.b0 + bz;
     if (d.nlive > 0 && bz >= d.nlive) return;
