@@ -1789,12 +1789,11 @@ constexpr int TAIL_BACKOFF = 30;     // x 64 cycles
 // counters' (stride 16) the polls still cost 6 us per sweep -- presumably the same L2 channel
 constexpr int TAIL_FLAG_STRIDE = 528;
 #define TAIL_FLAG_AT(B_, b_) ((size_t)(B_) * TAIL_STRIDE + (size_t)(b_) * TAIL_FLAG_STRIDE)
-#ifndef SE_CHUNK_WAVES12
-#define SE_CHUNK_WAVES12 3
-#endif
-constexpr int se_chunk_waves(int tsm, int ntc) { return ntc == 12 ? SE_CHUNK_WAVES12 : tsm == 2 ? 3 : 4; }
+// (No waves-per-SIMD bound here: stating the occupancy the compiler arrives at by itself -- three waves for the 12-chunk
+// instances, 158 VGPRs either way -- made k_se_chunk<2,12> 16 % slower at SYN-2048, 1 518 against 1 317 us per trajectory: the
+// scheduler clusters the tile's loads differently once it is given a target.  Four waves (128 VGPRs, 132 B of scratch): 1 477.)
 template <int TSM, int NTC>
-__global__ __launch_bounds__(256, se_chunk_waves(TSM, NTC))
+__global__ __launch_bounds__(256)
 void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsigned long long target, int traj) {
     const int ntile = d.ntc * d.nmt, n_tiles = ntile * d.aff_nb;
     if ((int)blockIdx.x < n_tiles) {
