@@ -1897,9 +1897,13 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
 // always drains.
 // ---------------------------------------------------------------------------------------------
 #ifndef LEAP_BACKOFF_N
-#define LEAP_BACKOFF_N 12
+#define LEAP_BACKOFF_N 48
 #endif
-constexpr int LEAP_BACKOFF = LEAP_BACKOFF_N;     // x 64 cycles slept before a tile first looks for the roles' tables
+constexpr int LEAP_BACKOFF = LEAP_BACKOFF_N;     // x 64 cycles slept before a tile first looks for the roles' tables: they come ~4 us
+                                                 // after its sums have left (12 / 24 / 36 / 48 / 72 / 100: 135.1 / 134.4 / 133.9 / 133.8 /
+                                                 // 133.7 / 133.5 us per launch at UK-380; NI-11, whose steps are shorter: level up to 48,
+                                                 // 108 against 95 at 100)
+constexpr int LEAP_BACKOFF_ROLE = 12;            // ... and a role before its second look at the tiles' flags (the trajectory's end)
 constexpr int LEAP_NSH = 8;          // counters / flag copies per chain, 128 bytes apart
 constexpr int LEAP_CH = 1024;        // 64-bit words of Chains::leap per chain
 #define LEAP_CNT1(b_, k_) (ch.leap + (size_t)(b_) * LEAP_CH + (k_) * 16)            // tiles counted in on shard k, over all launches
@@ -2374,7 +2378,7 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
             // (the first look at once: a role that reaches its wait after the tiles -- most do, their waves get few issue slots
             // while the tile waves of their SIMDs are at their cells -- must not sleep first; then the back-off, once)
             while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(flag1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stepno) != 0ull) {
-                if (spins == 0 && nwg >= 32) __builtin_amdgcn_s_sleep(LEAP_BACKOFF); else __builtin_amdgcn_s_sleep(1);
+                if (spins == 0 && nwg >= 32) __builtin_amdgcn_s_sleep(LEAP_BACKOFF_ROLE); else __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 if ((spins & 255) == 0 && __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // see leap_wait
                 if (spins > (1 << 21)) { if (lane_w == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
