@@ -937,7 +937,13 @@ __device__ __forceinline__ void pair_band_block(const Dims &d, const Consts &c, 
     const int r_lo = bx * rpb, r_hi = min(d.M, r_lo + rpb);
     // ---- the update accepted in this launch (token 4, early in the authoritative role): its descriptor, and what its F
     // band needs for this workgroup's rows -- coefficients and the F values themselves (nobody writes F but this code)
-    if (tid == 0) wait_token(done + 4, token, ch.late + ch.late_fatal + b);
+#ifndef PAIR_BAND_BACKOFF
+#define PAIR_BAND_BACKOFF 0
+#endif
+    if (tid == 0) {
+        if (PAIR_BAND_BACKOFF > 0) __builtin_amdgcn_s_sleep(PAIR_BAND_BACKOFF);   // (role 0 decides the pending update ~3.5 us into a step)
+        wait_token(done + 4, token, ch.late + ch.late_fatal + b);
+    }
     QSTAMP(st_slot, st_step, 1);
     __syncthreads();
     move_copy_l2(&fp, ch.fpend + b, 128);
@@ -1636,8 +1642,11 @@ __device__ __forceinline__ void pair_chain_barrier(const Chains &ch, int b, unsi
         if (old + 1u != target) {
             int spins = 0;
             unsigned *late = ch.late + ch.late_fatal + b;
+#ifndef PBAR_SLEEP
+#define PBAR_SLEEP 1
+#endif
             while ((int)(ld_l2(cnt) - target) < 0) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(PBAR_SLEEP);
                 ++spins;
                 if ((spins & 255) == 0 && ld_l2(late) != 0u) break;                          // (see wait_token)
                 if (spins > (1 << 22)) { __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // counted, no hang
