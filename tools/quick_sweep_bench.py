@@ -16,11 +16,12 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the sweep as a hipGraph")
     ap.add_argument("--variant", default="", help="tools/dev/variants/libseirhip_<variant>.so instead of the product library")
     args = ap.parse_args()
-    import __graft_entry__ as entry
-    entry.build()
-    if args.variant:
+    if args.variant:                                    # (BEFORE anything loads the product library: build() does)
         from covid19uk_amd import _lib
         _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev", "variants", f"libseirhip_{args.variant}.so")
+    else:
+        import __graft_entry__ as entry
+        entry.build()
     from covid19uk_amd import synth
     from covid19uk_amd.sampler import ChainSampler
     from covid19uk_amd.seir import SeirModel
