@@ -1882,14 +1882,18 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
 // only its 64 + 16 table entries and writes its partial sums.  Grid and roles as in k_se_chunk (tile blocks, then one
 // single-wave workgroup per 64-day / 64-row chunk role), all of a chain's workgroups on one XCD (checked at creation),
 // every workgroup of the launch resident at once (checked by the host through the occupancy query: tiles wait here).
-// Two one-directional hand-offs per step, both through the XCD's L2 without fences (see k_se_chunk), in the chain's
-// own block of Chains::leap.  Returning atomics on ONE address are served one after the other, ~26 ns apiece (timeline:
-// 144 tiles that finish together were counted in over 3.7 us), so the tiles count in on LEAP_NSH counters in lines of
-// their own (tile t on counter t mod 8) and whoever completes a counter raises that counter's flag:
-//   tiles -> roles  a role waits until all (up to) eight flags show the step (one load per lane 0..7, one ballot);
-//   roles -> tiles  one counter (twelve roles, each after its stores are acknowledged: s_waitcnt vmcnt(0)); the role that
-//                   completes the step's count writes the step number to eight flag words in eight lines, and a tile --
-//                   or a role, before it reads what the previous step's roles wrote -- polls copy (index mod 8).
+// Two one-directional hand-offs per step, both through the XCD's L2 without fences (see k_se_chunk).  Since the second half
+// of round 4 what is handed over travels as HAND-OFF WORDS (device_math.h / "Hand-off words" above: every value carries the
+// step's number, the consumer's load of the value is its wait) -- no acknowledged store, no ticket, no flag between tiles
+// and roles:
+//   tiles -> roles  column sums, row sums, psi parts, tile scalars (Chains::llK / llR / llP / llTS, two step parities);
+//   roles -> tiles  exp(a_t), exp(b_m)/N_m, spatial effects (M > 512), psi (Chains::llT).
+// The counters and flags of the first version remain, in the chain's own block of Chains::leap, for what still needs a count:
+// the roles among themselves (each counts in after its stores are acknowledged; the one that completes the step's count writes
+// the step number to eight flag words in eight lines; a role polls copy (index mod 8) before it reads what the previous
+// step's roles wrote), and the tiles' arrival at a launch's last step (Work::Lpart, plain, for the roles' accept test;
+// the tiles count in on LEAP_NSH counters in lines of their own -- returning atomics on ONE address are served one after the
+// other, ~26 ns apiece -- and whoever completes a counter raises that counter's flag).
 // Everything a workgroup reads that another workgroup of this launch wrote is read past the L1 (agent-scope loads).
 // The arithmetic is se_tile's and hmc_chunk_role's, operand for operand and in the same order: results are
 // bit-identical to k_se_chunk and to k_se + k_hmc_chunk (tests/test_sampler_gpu.py).
