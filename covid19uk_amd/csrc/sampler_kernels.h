@@ -1883,7 +1883,7 @@ void k_se_chunk(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par, unsi
 // single-wave workgroup per 64-day / 64-row chunk role), all of a chain's workgroups on one XCD (checked at creation),
 // every workgroup of the launch resident at once (checked by the host through the occupancy query: tiles wait here).
 // Two one-directional hand-offs per step, both through the XCD's L2 without fences (see k_se_chunk).  Since the second half
-// of round 4 what is handed over travels as HAND-OFF WORDS (device_math.h / "Hand-off words" above: every value carries the
+// of round 4 what is handed over travels as HAND-OFF WORDS ("Hand-off words" above: every value carries the
 // step's number, the consumer's load of the value is its wait) -- no acknowledged store, no ticket, no flag between tiles
 // and roles:
 //   tiles -> roles  column sums, row sums, psi parts, tile scalars (Chains::llK / llR / llP / llTS, two step parities);
