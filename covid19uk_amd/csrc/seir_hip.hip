@@ -536,7 +536,10 @@ static int launch_eval_all(seir_ctx *ctx, const LaunchCfg &l, const double *u_de
     // the reduction block runs inside the launch for value-only calls; with the gradient it is its own launch (measured:
     // the gradient assembly takes 12.7 us as the last block of this large kernel against 4.8 us in k_finish -- 59.2 us
     // per batch against 56.9)
-    const int fin = grad_dev ? 0 : 1;
+#ifndef EVAL_FIN_GRAD
+#define EVAL_FIN_GRAD 0
+#endif
+    const int fin = grad_dev ? EVAL_FIN_GRAD : 1;
     if (grad_dev)
         hipLaunchKernelGGL((k_eval_all<true, TN>), grid, dim3(512), lds, l.st, d, ctx->c, ctx->w, events_dev, u_dev, logp_dev,
                            grad_dev, ctx->eval_cnt, ctx->eval_a, ctx->eval_b, ctx->eval_err, fin);
