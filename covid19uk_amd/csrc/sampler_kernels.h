@@ -193,7 +193,17 @@ template <int N> __device__ __forceinline__ void ll_load(const uint4 *const (&p)
 // of the chain gives up at its next look at it; the values are then whatever was there -- the host discards the burst.
 // (Looking again at only the places that were late, one load at a time, was slower -- 140.7 us per launch against 134.7: with
 // several tiles late, each place's round trip came behind the last one's.)
-template <int N> __device__ __forceinline__ void ll_poll(const uint4 *const (&p)[N], unsigned seq, unsigned *late, double (&v)[N]) {
+#ifndef LEAP_ROLE_PRIO
+#define LEAP_ROLE_PRIO 3            // k_leap's role waves (see there)
+#endif
+#ifdef LL_POLL_DROP_PRIO
+#define LL_RPRIO LEAP_ROLE_PRIO
+#else
+#define LL_RPRIO -1
+#endif
+// RPRIO >= 0 (a role's waves): the wave's priority is dropped while it looks again and again, and put back to RPRIO when the
+// words are there
+template <int N, int RPRIO = -1> __device__ __forceinline__ void ll_poll(const uint4 *const (&p)[N], unsigned seq, unsigned *late, double (&v)[N]) {
     u32x4 x[N];
     int spins = 0;
     for (;;) {
@@ -202,6 +212,7 @@ template <int N> __device__ __forceinline__ void ll_poll(const uint4 *const (&p)
 #pragma unroll
         for (int j = 0; j < N; ++j) ok = ok && ll_ok(x[j], seq);
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        if (RPRIO >= 0 && spins == 0) __builtin_amdgcn_s_setprio(0);
 #ifndef LL_POLL_SLEEP
 #define LL_POLL_SLEEP 2
 #endif
@@ -210,6 +221,7 @@ template <int N> __device__ __forceinline__ void ll_poll(const uint4 *const (&p)
         if ((spins & 63) == 0 && __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         if (spins > (1 << 19)) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
+    if (RPRIO >= 0 && spins > 0) __builtin_amdgcn_s_setprio(RPRIO);
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] = ll_value(x[j]);
 }
@@ -963,9 +975,9 @@ struct LeapLL {
 };
 __device__ __forceinline__ size_t ll_tab_len(const Dims &d) { return (size_t)d.Tp + 2 * (size_t)d.Mp + 8; }
 // N places in groups of up to six loads
-template <int N> __device__ __forceinline__ void ll_poll_many(const uint4 *const (&p)[N], unsigned seq, unsigned *late, double (&v)[N]) {
+template <int N, int RPRIO = -1> __device__ __forceinline__ void ll_poll_many(const uint4 *const (&p)[N], unsigned seq, unsigned *late, double (&v)[N]) {
     if constexpr (N <= 6) {
-        ll_poll<N>(p, seq, late, v);
+        ll_poll<N, RPRIO>(p, seq, late, v);
     } else {
         constexpr int H = N / 2;
         const uint4 *pa[H], *pb_[N - H];
@@ -974,8 +986,8 @@ template <int N> __device__ __forceinline__ void ll_poll_many(const uint4 *const
         for (int j = 0; j < H; ++j) pa[j] = p[j];
 #pragma unroll
         for (int j = 0; j < N - H; ++j) pb_[j] = p[H + j];
-        ll_poll_many<H>(pa, seq, late, va);
-        ll_poll_many<N - H>(pb_, seq, late, vb);
+        ll_poll_many<H, RPRIO>(pa, seq, late, va);
+        ll_poll_many<N - H, RPRIO>(pb_, seq, late, vb);
 #pragma unroll
         for (int j = 0; j < H; ++j) v[j] = va[j];
 #pragma unroll
@@ -999,7 +1011,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
             double x[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) pp[jj] = kp + (size_t)min(wv + 4 * jj, nmt - 1) * d.Tp;
-            ll_poll<4>(pp, ll.seq_in, ll.late, x);
+            ll_poll<4, LL_RPRIO>(pp, ll.seq_in, ll.late, x);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) cw += wv + 4 * jj < nmt ? x[jj] : 0.0;
         } else {
@@ -1008,7 +1020,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
                 double x[6];
 #pragma unroll
                 for (int jj = 0; jj < 6; ++jj) pp[jj] = kp + (size_t)min(j0 + wv + 4 * jj, nmt - 1) * d.Tp;
-                ll_poll<6>(pp, ll.seq_in, ll.late, x);
+                ll_poll<6, LL_RPRIO>(pp, ll.seq_in, ll.late, x);
 #pragma unroll
                 for (int jj = 0; jj < 6; ++jj) cw += j0 + wv + 4 * jj < nmt ? x[jj] : 0.0;
             }
@@ -1022,7 +1034,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
             const uint4 *tp_ = TS + ((size_t)min(lane, nmt - 1) * ntc + min(cc, ntc - 1)) * 4;
             tp[2 * i] = tp_; tp[2 * i + 1] = tp_ + 1;
         }
-        ll_poll_many<2 * NI>(tp, ll.seq_in, ll.late, ba);
+        ll_poll_many<2 * NI, LL_RPRIO>(tp, ll.seq_in, ll.late, ba);
         g[G::C + wv * WAVE + lane] = cw;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -1040,7 +1052,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
             double x[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j) rp[j] = R + (size_t)min(j, ntc - 1) * d.Mp + (own ? m : 0);
-            ll_poll_many<NC>(rp, ll.seq_in, ll.late, x);
+            ll_poll_many<NC, LL_RPRIO>(rp, ll.seq_in, ll.late, x);
 #pragma unroll
             for (int j = 0; j < NC; ++j) g[G::X + j * WAVE + lane] = (own && j < ntc) ? x[j] : 0.0;
         }
@@ -1052,7 +1064,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
                 double x[4], y[4], z[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pp[j] = P + (i0 + j * WAVE < ntile ? i0 + j * WAVE : 0);
-                ll_poll<4>(pp, ll.seq_in, ll.late, x);
+                ll_poll<4, LL_RPRIO>(pp, ll.seq_in, ll.late, x);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { if (!(i0 + j * WAVE < ntile)) x[j] = 0.0; y[j] = 0.0; z[j] = 0.0; }
                 if (!rows_here) {                                // uniform
@@ -1062,8 +1074,8 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
                         const int ic = i0 + j * WAVE < ntile ? i0 + j * WAVE : 0;
                         yp[j] = TS + (size_t)ic * 4 + 2; zp[j] = TS + (size_t)ic * 4 + 3;
                     }
-                    ll_poll<4>(yp, ll.seq_in, ll.late, y);
-                    ll_poll<4>(zp, ll.seq_in, ll.late, z);
+                    ll_poll<4, LL_RPRIO>(yp, ll.seq_in, ll.late, y);
+                    ll_poll<4, LL_RPRIO>(zp, ll.seq_in, ll.late, z);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (!(i0 + j * WAVE < ntile)) { y[j] = 0.0; z[j] = 0.0; }
                 }
@@ -1083,7 +1095,7 @@ __device__ __forceinline__ void role_gather(const Dims &d, const Chains &ch, con
                 double x[NC];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) rp[j] = R + (size_t)(j < ntc ? j : 0) * d.Mp + (on ? mm : 0);
-                ll_poll_many<NC>(rp, ll.seq_in, ll.late, x);
+                ll_poll_many<NC, LL_RPRIO>(rp, ll.seq_in, ll.late, x);
                 double acc = 0.0;
 #pragma unroll
                 for (int j = 0; j < NC; ++j) acc += (on && j < ntc) ? x[j] : 0.0;
@@ -2343,9 +2355,6 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
     // with it, while the tiles -- since the hand-off words -- are back at their cells before the roles have finished counting
     // in, and a wave that gets an issue slot only when three dense fp64 waves leave one took 1.5 us for its last ten instructions
     // (141 -> 135 us per launch; measured level while the tiles still waited for the roles' flag)
-#ifndef LEAP_ROLE_PRIO
-#define LEAP_ROLE_PRIO 3
-#endif
     __builtin_amdgcn_s_setprio(LEAP_ROLE_PRIO);
 #ifdef LEAP_HELPER_PRIO                            // (developer builds: the helper waves at another priority than the role's own)
     if ((threadIdx.x >> 6) != 0) __builtin_amdgcn_s_setprio(LEAP_HELPER_PRIO);
@@ -2391,7 +2400,15 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
         if (wv != 0) {
             // the helper waves: the rows' spatial effects of the current position once the previous step's roles are done
             // (the first step of a folded trajectory reads q itself), then the partial sums once the tiles are in
-            if (it > 0) leap_wait(flag2, role_base + (unsigned long long)it, late);
+            if (it > 0) {
+#ifndef LEAP_WAIT_KEEP_PRIO
+                __builtin_amdgcn_s_setprio(0);        // (asleep-and-look: not ahead of the tiles it shares the SIMD with)
+#endif
+                leap_wait(flag2, role_base + (unsigned long long)it, late);
+#ifndef LEAP_WAIT_KEEP_PRIO
+                __builtin_amdgcn_s_setprio(LEAP_ROLE_PRIO);
+#endif
+            }
             {
                 const bool first_ = (fold & 1) && it == 0;
                 const double *spr_ = first_ ? ch.q0 + (size_t)b * d.Pp + 6 + d.T - 1 : w.sp + ((size_t)b * 2 + par) * d.Mp;
@@ -2402,7 +2419,15 @@ void k_leap(Dims d, Consts c, Work w, SamplerCfg s, Chains ch, int par0, int nst
             continue;
         }
         // what the roles of the previous step wrote (chunk sums, global parameters, spatial effects, q and p)
-        if (it > 0) leap_wait(flag2, role_base + (unsigned long long)it, late);
+        if (it > 0) {
+#ifndef LEAP_WAIT_KEEP_PRIO
+            __builtin_amdgcn_s_setprio(0);            // (asleep-and-look: not ahead of the tiles it shares the SIMD with: 133.9 -> 132.7 us)
+#endif
+            leap_wait(flag2, role_base + (unsigned long long)it, late);
+#ifndef LEAP_WAIT_KEEP_PRIO
+            __builtin_amdgcn_s_setprio(LEAP_ROLE_PRIO);
+#endif
+        }
         RPROBE(0);                                               // the previous step's roles are done
         hmc_chunk_role<NTC, true, true>(d, c, w, s, ch, par, role, b, [&] {
             if (threadIdx.x == 0) { LSTAMP_MIN(4); LSTAMP_MAX(5); }
